@@ -1,0 +1,134 @@
+"""ctypes binding of the renderer's C ABI (include/rt_api.h).
+
+The shared library is built in-tree by csrc/Makefile.  There is no CPU fallback: if the library is missing or
+the GPU call fails, the error is raised.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import ctypes_types as T
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "librt_amd.so")
+
+RT_TILE = 64
+_lib = None
+
+
+class RtError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads librt_amd.so (once).  torch, when used in the same process, must be imported first so that both
+    share one HIP runtime; the caller decides that, this module never imports torch."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtError(f"{LIB_PATH} is missing: build it with `make -C {os.path.dirname(LIB_PATH)}`")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    vp, i32, sz = C.c_void_p, C.c_int, C.c_size_t
+    L.rt_last_error.restype = C.c_char_p
+    L.rt_create.argtypes = [i32, C.POINTER(i32), C.POINTER(vp)]
+    L.rt_destroy.argtypes = [vp]
+    L.rt_destroy.restype = None
+    L.rt_upload_scene.argtypes = [vp, C.POINTER(T.SceneDesc)]
+    L.rt_update_frame_state.argtypes = [vp, C.POINTER(T.Camera), C.POINTER(T.Config), C.POINTER(T.Dynamic)]
+    L.rt_render_frame.argtypes = [vp, i32, i32, vp, C.POINTER(T.FrameStats)]
+    L.rt_render_frame_ids.argtypes = [vp, i32, i32, vp, vp, vp, C.POINTER(T.FrameStats)]
+    L.rt_render_device.argtypes = [vp, i32, i32, vp, vp]
+    L.rt_tile_buffer_bytes.argtypes = [i32, i32, i32]
+    L.rt_tile_buffer_bytes.restype = sz
+    L.rt_render_tiles_device.argtypes = [vp, i32, i32, i32, i32, vp, sz, vp]
+    L.rt_untile_device.argtypes = [vp, i32, i32, i32, vp, vp, vp]
+    L.rt_count_rays.argtypes = [vp, i32, i32, C.POINTER(T.FrameStats)]
+    L.rt_get_scene_info.argtypes = [vp, C.POINTER(T.SceneInfo)]
+    L.rt_camera_look.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.POINTER(T.Camera)]
+    L.rt_bake_model.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, C.POINTER(C.c_float), i32,
+                                vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RtError(f"rt error {rc}: {lib().rt_last_error().decode()}")
+
+
+def camera_look(position, fov=90.0, yaw=-90.0, pitch=0.0):
+    """Camera basis exactly as the host library computes it (Camera.cpp:5-20, 54-63)."""
+    cam = T.Camera()
+    pos = (C.c_float * 3)(*[float(v) for v in position])
+    _check(lib().rt_camera_look(pos, float(fov), float(yaw), float(pitch), C.byref(cam)))
+    return cam
+
+
+class Renderer:
+    """One GPU context: upload a scene, set the frame state, render."""
+
+    def __init__(self, device=0):
+        self._ctx = C.c_void_p()
+        dev = (C.c_int * 1)(int(device))
+        _check(lib().rt_create(1, dev, C.byref(self._ctx)))
+
+    def close(self):
+        if self._ctx:
+            lib().rt_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, scene_desc):
+        _check(lib().rt_upload_scene(self._ctx, C.byref(scene_desc)))
+
+    def set_state(self, camera, config, dynamic=None):
+        _check(lib().rt_update_frame_state(self._ctx, C.byref(camera), C.byref(config),
+                                           C.byref(dynamic) if dynamic is not None else None))
+
+    def render(self, width, height):
+        """Returns (rgb uint8 [h, w, 3], FrameStats)."""
+        rgb = np.empty((height, width, 3), dtype=np.uint8)
+        st = T.FrameStats()
+        _check(lib().rt_render_frame(self._ctx, width, height, rgb.ctypes.data, C.byref(st)))
+        return rgb, st
+
+    def render_ids(self, width, height):
+        """Returns (rgb, ids int32 [h, w, 2], t float32 [h, w], FrameStats) from the instrumented kernel."""
+        rgb = np.empty((height, width, 3), dtype=np.uint8)
+        ids = np.empty((height, width, 2), dtype=np.int32)
+        t = np.empty((height, width), dtype=np.float32)
+        st = T.FrameStats()
+        _check(lib().rt_render_frame_ids(self._ctx, width, height, rgb.ctypes.data, ids.ctypes.data, t.ctypes.data, C.byref(st)))
+        return rgb, ids, t, st
+
+    def count_rays(self, width, height):
+        st = T.FrameStats()
+        _check(lib().rt_count_rays(self._ctx, width, height, C.byref(st)))
+        return st
+
+    def render_device(self, width, height, d_rgb_ptr, stream=None):
+        _check(lib().rt_render_device(self._ctx, width, height, C.c_void_p(d_rgb_ptr), C.c_void_p(stream or 0)))
+
+    def render_tiles_device(self, width, height, rank, world, d_tiles_ptr, capacity, stream=None):
+        _check(lib().rt_render_tiles_device(self._ctx, width, height, rank, world, C.c_void_p(d_tiles_ptr), capacity,
+                                            C.c_void_p(stream or 0)))
+
+    def untile_device(self, width, height, world, d_gathered_ptr, d_rgb_ptr, stream=None):
+        _check(lib().rt_untile_device(self._ctx, width, height, world, C.c_void_p(d_gathered_ptr), C.c_void_p(d_rgb_ptr),
+                                      C.c_void_p(stream or 0)))
+
+    def scene_info(self):
+        info = T.SceneInfo()
+        _check(lib().rt_get_scene_info(self._ctx, C.byref(info)))
+        return info
+
+
+def tile_buffer_bytes(width, height, world):
+    return int(lib().rt_tile_buffer_bytes(width, height, world))

@@ -1,0 +1,348 @@
+// C ABI of the renderer (see include/rt_api.h for the contract and the reference call sites each entry replaces).
+#include "rt_api.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "rt_device_types.h"
+#include "rt_kernels.h"
+#include "rt_scene.h"
+
+static_assert(RT_TILE == RT_TILE_PX, "public and internal tile sizes must agree");
+
+namespace {
+
+thread_local std::string g_lastError;
+
+int fail(int code, const std::string& msg) { g_lastError = msg; return code; }
+
+int failHip(hipError_t e, const char* what) {
+    return fail(RT_ERR_DEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define RT_HIP(call)                                         \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return failHip(e_, #call);     \
+    } while (0)
+
+template <typename T>
+int uploadArray(const std::vector<T>& host, const T** devOut, std::vector<void*>& allocs, int64_t& bytes) {
+    *devOut = nullptr;
+    if (host.empty()) return RT_OK;
+    void* p = nullptr;
+    RT_HIP(hipMalloc(&p, host.size() * sizeof(T)));
+    allocs.push_back(p);
+    RT_HIP(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+    bytes += (int64_t)(host.size() * sizeof(T));
+    *devOut = static_cast<const T*>(p);
+    return RT_OK;
+}
+
+}  // namespace
+
+struct rt_ctx {
+    int device = 0;
+    bool haveScene = false, haveState = false;
+    rt::DevScene scene{};
+    rt::FrameParams frame{};
+    rt_scene_info info{};
+    std::vector<void*> sceneAllocs;
+    // frame-owned scratch for the host-pointer entry points
+    uint8_t* dFrame = nullptr; size_t frameCap = 0;
+    int32_t* dIds = nullptr; size_t idsCap = 0;
+    float* dT = nullptr; size_t tCap = 0;
+    unsigned long long* dCounters = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    // host copies of the small tables that rt_update_frame_state may rewrite
+    rt::F4 sphere0Geom{}; bool hasSphere0 = false;
+    rt::F4 plane0Mat0{}; bool hasPlane0 = false;
+};
+
+namespace {
+
+void freeScene(rt_ctx* c) {
+    for (void* p : c->sceneAllocs) (void)hipFree(p);
+    c->sceneAllocs.clear();
+    c->scene = rt::DevScene{};
+    c->haveScene = false;
+}
+
+int tilesAlong(int pixels) { return (pixels + RT_TILE - 1) / RT_TILE; }
+
+int ownedTileCount(int tiles, int rank, int world) {
+    if (rank >= tiles) return 0;
+    return (tiles - rank + world - 1) / world;
+}
+
+int checkFrameArgs(rt_ctx* ctx, int width, int height) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    if (width <= 0 || height <= 0 || width > 65536 || height > 65536) return fail(RT_ERR_INVALID, "frame size out of range");
+    if (!ctx->haveScene) return fail(RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    if (!ctx->haveState) return fail(RT_ERR_NO_STATE, "rt_update_frame_state has not been called");
+    return RT_OK;
+}
+
+rt::FrameParams frameFor(const rt_ctx* ctx, int width, int height, int rank, int world, bool compact) {
+    rt::FrameParams p = ctx->frame;
+    p.width = width; p.height = height;
+    p.rank = rank; p.world = world;
+    p.tilesX = tilesAlong(width); p.tilesY = tilesAlong(height);
+    p.ownedTiles = ownedTileCount(p.tilesX * p.tilesY, rank, world);
+    p.compactOutput = compact ? 1 : 0;
+    return p;
+}
+
+template <typename T>
+int ensureCapacity(T** buf, size_t* cap, size_t need) {
+    if (*cap >= need) return RT_OK;
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+    void* p = nullptr;
+    RT_HIP(hipMalloc(&p, need * sizeof(T)));
+    *buf = static_cast<T*>(p);
+    *cap = need;
+    return RT_OK;
+}
+
+int renderToHost(rt_ctx* ctx, int width, int height, uint8_t* rgbOut, int32_t* idsOut, float* tOut, bool instrumented,
+                 rt_frame_stats* stats) {
+    int rc = checkFrameArgs(ctx, width, height);
+    if (rc) return rc;
+    RT_HIP(hipSetDevice(ctx->device));
+    const size_t pixels = (size_t)width * (size_t)height;
+    rc = ensureCapacity(&ctx->dFrame, &ctx->frameCap, pixels * 3);
+    if (rc) return rc;
+    if (idsOut) { rc = ensureCapacity(&ctx->dIds, &ctx->idsCap, pixels * 2); if (rc) return rc; }
+    if (tOut) { rc = ensureCapacity(&ctx->dT, &ctx->tCap, pixels); if (rc) return rc; }
+
+    rt::FrameParams p = frameFor(ctx, width, height, 0, 1, false);
+    RT_HIP(hipMemsetAsync(ctx->dCounters, 0, sizeof(unsigned long long) * rt::kCntCount, nullptr));
+    RT_HIP(hipEventRecord(ctx->evStart, nullptr));
+    RT_HIP(rt::launchRender(ctx->scene, p, ctx->dFrame, idsOut ? ctx->dIds : nullptr, tOut ? ctx->dT : nullptr, ctx->dCounters,
+                            instrumented, nullptr));
+    RT_HIP(hipEventRecord(ctx->evStop, nullptr));
+    if (rgbOut) RT_HIP(hipMemcpyAsync(rgbOut, ctx->dFrame, pixels * 3, hipMemcpyDeviceToHost, nullptr));
+    if (idsOut) RT_HIP(hipMemcpyAsync(idsOut, ctx->dIds, pixels * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
+    if (tOut) RT_HIP(hipMemcpyAsync(tOut, ctx->dT, pixels * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    unsigned long long counters[rt::kCntCount];
+    RT_HIP(hipMemcpyAsync(counters, ctx->dCounters, sizeof counters, hipMemcpyDeviceToHost, nullptr));
+    RT_HIP(hipStreamSynchronize(nullptr));
+    if (stats) {
+        float ms = 0.0f;
+        RT_HIP(hipEventElapsedTime(&ms, ctx->evStart, ctx->evStop));
+        stats->gpu_ms = ms;
+        stats->rays = counters[rt::kCntRays];
+        stats->node_tests = counters[rt::kCntNodeTests];
+        stats->tri_tests = counters[rt::kCntTriTests];
+        stats->attr_fetches = counters[rt::kCntAttrFetches];
+        stats->gate_tests = counters[rt::kCntGateTests];
+    }
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_last_error(void) { return g_lastError.c_str(); }
+
+int rt_create(int device_count, const int* devices, rt_ctx** out) {
+    if (!out) return fail(RT_ERR_INVALID, "null output pointer");
+    *out = nullptr;
+    if (device_count != 1 || !devices) return fail(RT_ERR_INVALID, "device_count must be 1 (one context per GPU)");
+    int n = 0;
+    RT_HIP(hipGetDeviceCount(&n));
+    if (devices[0] < 0 || devices[0] >= n) return fail(RT_ERR_INVALID, "no such HIP device");
+    RT_HIP(hipSetDevice(devices[0]));
+    rt_ctx* c = new (std::nothrow) rt_ctx();
+    if (!c) return fail(RT_ERR_INVALID, "out of host memory");
+    c->device = devices[0];
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, sizeof(unsigned long long) * rt::kCntCount);
+    if (e != hipSuccess) { delete c; return failHip(e, "hipMalloc(counters)"); }
+    c->dCounters = static_cast<unsigned long long*>(p);
+    e = hipEventCreate(&c->evStart);
+    if (e == hipSuccess) e = hipEventCreate(&c->evStop);
+    if (e != hipSuccess) { rt_destroy(c); return failHip(e, "hipEventCreate"); }
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    freeScene(ctx);
+    if (ctx->dFrame) (void)hipFree(ctx->dFrame);
+    if (ctx->dIds) (void)hipFree(ctx->dIds);
+    if (ctx->dT) (void)hipFree(ctx->dT);
+    if (ctx->dCounters) (void)hipFree(ctx->dCounters);
+    if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
+    if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
+    delete ctx;
+}
+
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
+    if (!ctx || !scene) return fail(RT_ERR_INVALID, "null argument");
+    rt::FlatScene flat;
+    std::string err;
+    if (!rt::flattenScene(*scene, flat, err)) return fail(RT_ERR_INVALID, err);
+
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipDeviceSynchronize());
+    freeScene(ctx);
+    rt::DevScene d{};
+    int64_t bytes = 0;
+    int rc = 0;
+    auto& A = ctx->sceneAllocs;
+    if ((rc = uploadArray(flat.sphGeom, &d.sphGeom, A, bytes)) || (rc = uploadArray(flat.sphMat, &d.sphMat, A, bytes)) ||
+        (rc = uploadArray(flat.plnP, &d.plnP, A, bytes)) || (rc = uploadArray(flat.plnN, &d.plnN, A, bytes)) ||
+        (rc = uploadArray(flat.plnMat, &d.plnMat, A, bytes)) || (rc = uploadArray(flat.boxMin, &d.boxMin, A, bytes)) ||
+        (rc = uploadArray(flat.boxMax, &d.boxMax, A, bytes)) || (rc = uploadArray(flat.boxMat, &d.boxMat, A, bytes)) ||
+        (rc = uploadArray(flat.mdlGateMin, &d.mdlGateMin, A, bytes)) || (rc = uploadArray(flat.mdlGateMax, &d.mdlGateMax, A, bytes)) ||
+        (rc = uploadArray(flat.mdlTightMin, &d.mdlTightMin, A, bytes)) || (rc = uploadArray(flat.mdlTightMax, &d.mdlTightMax, A, bytes)) ||
+        (rc = uploadArray(flat.mdlMat, &d.mdlMat, A, bytes)) || (rc = uploadArray(flat.mdlInfo, &d.mdlInfo, A, bytes)) ||
+        (rc = uploadArray(flat.nodes, &d.nodes, A, bytes)) || (rc = uploadArray(flat.tris, &d.tris, A, bytes)) ||
+        (rc = uploadArray(flat.attrs, &d.attrs, A, bytes))) {
+        freeScene(ctx);
+        return rc;
+    }
+    d.nSph = scene->sphereCount; d.nPln = scene->planeCount; d.nBox = scene->AABBCount; d.nMdl = scene->modelCount;
+    std::memcpy(d.lightPos, flat.lightPos, sizeof d.lightPos);
+    std::memcpy(d.lightCol, flat.lightCol, sizeof d.lightCol);
+    ctx->scene = d;
+    ctx->haveScene = true;
+    ctx->hasSphere0 = !flat.sphGeom.empty();
+    if (ctx->hasSphere0) ctx->sphere0Geom = flat.sphGeom[0];
+    ctx->hasPlane0 = !flat.plnMat.empty();
+    if (ctx->hasPlane0) ctx->plane0Mat0 = flat.plnMat[0];
+
+    rt_scene_info& in = ctx->info;
+    in.sphereCount = d.nSph; in.planeCount = d.nPln; in.AABBCount = d.nBox; in.modelCount = d.nMdl;
+    in.triangleCount = flat.triangleCount; in.nodeCount = flat.nodeCount; in.leafCount = flat.leafCount;
+    in.maxDepth = flat.maxDepth; in.deviceBytes = bytes;
+    return RT_OK;
+}
+
+int rt_update_frame_state(rt_ctx* ctx, const rt_camera* cam, const rt_config* cfg, const rt_dynamic* dyn) {
+    if (!ctx || !cam || !cfg) return fail(RT_ERR_INVALID, "null argument");
+    if (cfg->softShadowNum < 0 || cfg->softShadowNum > 4096) return fail(RT_ERR_INVALID, "softShadowNum out of range");
+    rt::FrameParams& p = ctx->frame;
+    const float* src[4] = {&cam->position.x, &cam->up.x, &cam->right.x, &cam->direction.x};
+    float* dst[4] = {p.camPos, p.camUp, p.camRight, p.camDir};
+    for (int i = 0; i < 4; i++) std::memcpy(dst[i], src[i], 3 * sizeof(float));
+    p.fovFactor = cam->fovFactor;
+    p.shadowBias = cfg->shadowBias; p.shadowIntensity = cfg->shadowIntensity;
+    p.sphereStrength = cfg->sphereReflectionStrength; p.planeStrength = cfg->planeReflectionStrength;
+    p.boxStrength = cfg->AABBReflectionStrength; p.modelStrength = cfg->modelReflectionStrength;
+    p.background[0] = cfg->backgroundCol.x; p.background[1] = cfg->backgroundCol.y; p.background[2] = cfg->backgroundCol.z;
+    p.softRadius = (float)cfg->softShadowRadius;
+    p.softNum = cfg->softShadowNum; p.maxDepth = cfg->maxDepth;
+    uint32_t f = 0;
+    if (cfg->renderHardShadows) f |= rt::kCfgHardShadows;
+    if (cfg->renderSoftShadows) f |= rt::kCfgSoftShadows;
+    if (cfg->areaLightSpecularEffect) f |= rt::kCfgAreaSpecular;
+    if (cfg->reflections) f |= rt::kCfgReflections;
+    if (cfg->reflectPlanes) f |= rt::kCfgReflectPlanes;
+    if (cfg->renderAABBs) f |= rt::kCfgRenderBoxes;
+    if (cfg->renderModels) f |= rt::kCfgRenderModels;
+    if (cfg->ambientLighting) f |= rt::kCfgAmbient;
+    if (cfg->diffuseLighting) f |= rt::kCfgDiffuse;
+    if (cfg->specularLighting) f |= rt::kCfgSpecular;
+    if (cfg->antiAliasing) f |= rt::kCfgAntiAlias;
+    if (cfg->cullBackTriangles) f |= rt::kCfgCull;
+    // Mesh modes (Model.cpp:161-357).  `octree` and `boundingBox` both select the accelerated whole-model-box path:
+    // the reference's octree branch is an unfinished stub that hides every mesh, so the flag is honoured as
+    // "use the octree", which is what this library always does.  The eight-box and no-box modes are not
+    // implemented by the kernels and are rejected rather than silently rendered differently.
+    if (cfg->octree || cfg->boundingBox) {
+        if (!cfg->octree && cfg->eightBoundingBoxes) return fail(RT_ERR_INVALID, "eightBoundingBoxes mesh mode is not supported");
+        f |= rt::kCfgModelsVisible;
+    } else {
+        return fail(RT_ERR_INVALID, cfg->eightBoundingBoxes ? "eightBoundingBoxes mesh mode is not supported"
+                                                            : "mesh mode without bounding box is not supported");
+    }
+    p.flags = f;
+
+    if (dyn && ctx->haveScene) {
+        RT_HIP(hipSetDevice(ctx->device));
+        if (dyn->setLight) {
+            ctx->scene.lightPos[0] = dyn->lightPosition.x; ctx->scene.lightPos[1] = dyn->lightPosition.y; ctx->scene.lightPos[2] = dyn->lightPosition.z;
+        }
+        if (dyn->setSphere0 && ctx->hasSphere0) {
+            ctx->sphere0Geom = rt::F4{dyn->sphere0Position.x, dyn->sphere0Position.y, dyn->sphere0Position.z, dyn->sphere0Radius};
+            RT_HIP(hipMemcpy(const_cast<rt::F4*>(ctx->scene.sphGeom), &ctx->sphere0Geom, sizeof(rt::F4), hipMemcpyHostToDevice));
+        }
+        if (dyn->setPlane0 && ctx->hasPlane0) {
+            ctx->plane0Mat0.x = dyn->plane0AmbientColour.x; ctx->plane0Mat0.y = dyn->plane0AmbientColour.y; ctx->plane0Mat0.z = dyn->plane0AmbientColour.z;
+            RT_HIP(hipMemcpy(const_cast<rt::F4*>(ctx->scene.plnMat), &ctx->plane0Mat0, sizeof(rt::F4), hipMemcpyHostToDevice));
+        }
+    }
+    ctx->haveState = true;
+    return RT_OK;
+}
+
+int rt_render_frame(rt_ctx* ctx, int width, int height, uint8_t* rgb_out, rt_frame_stats* stats) {
+    if (!rgb_out) return fail(RT_ERR_INVALID, "null output buffer");
+    return renderToHost(ctx, width, height, rgb_out, nullptr, nullptr, false, stats);
+}
+
+int rt_render_frame_ids(rt_ctx* ctx, int width, int height, uint8_t* rgb_out, int32_t* ids_out, float* t_out, rt_frame_stats* stats) {
+    return renderToHost(ctx, width, height, rgb_out, ids_out, t_out, true, stats);
+}
+
+int rt_count_rays(rt_ctx* ctx, int width, int height, rt_frame_stats* stats) {
+    if (!stats) return fail(RT_ERR_INVALID, "null stats");
+    return renderToHost(ctx, width, height, nullptr, nullptr, nullptr, true, stats);
+}
+
+int rt_render_device(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_stream) {
+    int rc = checkFrameArgs(ctx, width, height);
+    if (rc) return rc;
+    if (!d_rgb) return fail(RT_ERR_INVALID, "null device buffer");
+    rt::FrameParams p = frameFor(ctx, width, height, 0, 1, false);
+    RT_HIP(rt::launchRender(ctx->scene, p, static_cast<uint8_t*>(d_rgb), nullptr, nullptr, nullptr, false, static_cast<hipStream_t>(hip_stream)));
+    return RT_OK;
+}
+
+size_t rt_tile_buffer_bytes(int width, int height, int world) {
+    if (width <= 0 || height <= 0 || world <= 0) return 0;
+    int tiles = tilesAlong(width) * tilesAlong(height);
+    int perRank = (tiles + world - 1) / world;   // rank 0 owns the most tiles; every rank's buffer has this size
+    return (size_t)perRank * RT_TILE * RT_TILE * 3;
+}
+
+int rt_render_tiles_device(rt_ctx* ctx, int width, int height, int rank, int world, void* d_tiles, size_t capacity_bytes, void* hip_stream) {
+    int rc = checkFrameArgs(ctx, width, height);
+    if (rc) return rc;
+    if (world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "rank/world out of range");
+    if (!d_tiles) return fail(RT_ERR_INVALID, "null device buffer");
+    if (capacity_bytes < rt_tile_buffer_bytes(width, height, world)) return fail(RT_ERR_CAPACITY, "tile buffer too small");
+    rt::FrameParams p = frameFor(ctx, width, height, rank, world, true);
+    RT_HIP(rt::launchRender(ctx->scene, p, static_cast<uint8_t*>(d_tiles), nullptr, nullptr, nullptr, false, static_cast<hipStream_t>(hip_stream)));
+    return RT_OK;
+}
+
+int rt_untile_device(rt_ctx* ctx, int width, int height, int world, const void* d_gathered, void* d_rgb, void* hip_stream) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    if (width <= 0 || height <= 0 || world <= 0) return fail(RT_ERR_INVALID, "bad frame or world size");
+    if (!d_gathered || !d_rgb) return fail(RT_ERR_INVALID, "null device buffer");
+    RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb), width, height, world, tilesAlong(width),
+                            rt_tile_buffer_bytes(width, height, world), static_cast<hipStream_t>(hip_stream)));
+    return RT_OK;
+}
+
+int rt_get_scene_info(rt_ctx* ctx, rt_scene_info* info) {
+    if (!ctx || !info) return fail(RT_ERR_INVALID, "null argument");
+    if (!ctx->haveScene) return fail(RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    *info = ctx->info;
+    return RT_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Device-side data layout of a flattened scene, shared by the host flattener and the gfx950 kernels.
+//
+// Everything a ray touches lives in HBM as 16-byte-aligned float4 / uint4 arrays (struct-of-arrays: one array
+// per field group), so that a lane fetches a record with a few dwordx4 loads and uniform loops over the small
+// analytic-object tables turn into scalar loads.
+#pragma once
+#include <stdint.h>
+
+namespace rt {
+
+// ---- octree ----
+// One node is 256 bytes (two 128-byte cache lines) and describes its eight child octants:
+//   f4[0..1]  lo.x of children 0-3, 4-7      f4[6..7]   hi.x
+//   f4[2..3]  lo.y                           f4[8..9]   hi.y
+//   f4[4..5]  lo.z                           f4[10..11] hi.z
+//   u4[12..13] leafRef[8]: first triangle of a leaf child in the leaf-ordered triangle array
+//   u4[14]    { childBase, internalMask | leafMask << 8, 0, 0 }
+//   u4[15]    unused
+// Internal children are stored contiguously from childBase in slot order, so child slot c is node
+// childBase + popcount(internalMask & ((1 << c) - 1)).  Empty slots hold an inverted box (lo = +inf, hi = -inf).
+// Slot c is the octant (x > cx) | (y > cy) << 1 | (z > cz) << 2 of the node's split point.
+constexpr int kNodeFloat4s = 16;
+constexpr uint32_t kLeafFlag = 0x80000000u;   // in a model's root reference: the root is a leaf
+constexpr uint32_t kNoRoot = 0xFFFFFFFFu;     // model without triangles
+constexpr int kMaxOctreeDepth = 12;           // levels of internal nodes the traversal stack can hold
+
+// ---- triangles ----
+// Leaf-ordered, 3 float4 per triangle: { v0.xyz, bits(id) }, { e1.xyz, 0 }, { e2.xyz, 0 } with e1 = v1 - v0 and
+// e2 = v2 - v0 computed in float on the host (the same subtraction the intersection routine starts with).
+// id = triangle index inside its model; bit 31 marks the last triangle of a leaf.
+constexpr uint32_t kTriLast = 0x80000000u;
+// Attributes for shading, 7 float4 per triangle, indexed by triBase(model) + id:
+//   { n0.xyz, ka0.x } { n1.xyz, ka0.y } { n2.xyz, ka0.z } { ka1.xyz, kd0.x } { ka2.xyz, kd0.y } { kd1.xyz, kd0.z } { kd2.xyz, 0 }
+constexpr int kAttrFloat4s = 7;
+
+struct F4 { float x, y, z, w; };
+
+// Pointers + counts handed to every kernel by value.
+struct DevScene {
+    // spheres: geom = { centre.xyz, radius }
+    const F4* sphGeom;
+    // materials, three float4 per object of any kind:
+    //   m0 = { ambientColour.rgb, ambient }  m1 = { diffuseColour.rgb, diffuse }
+    //   m2 = { specular, shininess, bits(objectType), bits(flags) }   flags: 1 = debug, 2 = skipped by the ignore test
+    const F4* sphMat;
+    // planes: p = { position.xyz, 0 }, n = { n.xyz, 0 }
+    const F4* plnP;
+    const F4* plnN;
+    const F4* plnMat;
+    // boxes
+    const F4* boxMin;
+    const F4* boxMax;
+    const F4* boxMat;
+    // models: gate box (exact reference semantics), tight box of the triangles, material, info
+    const F4* mdlGateMin;
+    const F4* mdlGateMax;
+    const F4* mdlTightMin;
+    const F4* mdlTightMax;
+    const F4* mdlMat;          // same 3-float4 material layout
+    const uint32_t* mdlInfo;   // 4 per model: { rootRef, triBase, 0, 0 }
+    const F4* nodes;
+    const F4* tris;
+    const F4* attrs;
+    int32_t nSph, nPln, nBox, nMdl;
+    float lightPos[3];
+    float lightCol[3];
+};
+
+// Per-frame state handed to the render kernel by value.
+struct FrameParams {
+    int32_t width, height;
+    // tile sharding: this launch renders tiles rank, rank + world, ... ; tilesX/tilesY = tile grid
+    int32_t rank, world, tilesX, tilesY, ownedTiles;
+    int32_t compactOutput;     // 1: write tile-major into the rank's compact buffer, 0: row-major full frame
+    float camPos[3], camUp[3], camRight[3], camDir[3], fovFactor;
+    // SceneConfig
+    float shadowBias, shadowIntensity;
+    float sphereStrength, planeStrength, boxStrength, modelStrength;
+    float background[3];
+    float softRadius;
+    int32_t softNum, maxDepth;
+    uint32_t flags;            // kCfg* bits
+};
+
+enum : uint32_t {
+    kCfgHardShadows = 1u << 0, kCfgSoftShadows = 1u << 1, kCfgAreaSpecular = 1u << 2, kCfgReflections = 1u << 3,
+    kCfgReflectPlanes = 1u << 4, kCfgRenderBoxes = 1u << 5, kCfgRenderModels = 1u << 6, kCfgAmbient = 1u << 7,
+    kCfgDiffuse = 1u << 8, kCfgSpecular = 1u << 9, kCfgAntiAlias = 1u << 10, kCfgCull = 1u << 11,
+    kCfgModelsVisible = 1u << 12   // false when the selected mesh mode renders nothing
+};
+
+// Per-launch counters (one 64-bit word each), accumulated with one atomic per wave.
+enum { kCntRays = 0, kCntNodeTests, kCntTriTests, kCntAttrFetches, kCntGateTests, kCntCount };
+
+}  // namespace rt

@@ -1,0 +1,20 @@
+// Host-callable launchers of the gfx950 kernels (defined in rt_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device_types.h"
+
+#define RT_TILE_PX 64   // must equal RT_TILE of the public header
+
+namespace rt {
+
+// Renders the tiles FrameParams says this launch owns.  `out` is either the full row-major frame or the rank's
+// compact tile buffer (P.compactOutput).  ids / tbuf / counters may be null.  stats selects the instrumented kernel.
+hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
+                        unsigned long long* counters, bool stats, hipStream_t stream);
+
+hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX,
+                        size_t perRankBytes, hipStream_t stream);
+
+}  // namespace rt

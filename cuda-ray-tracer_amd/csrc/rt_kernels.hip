@@ -1,0 +1,745 @@
+// gfx950 render kernels: one lane per pixel, one wave per 8x8 pixel tile.
+//
+// Behavioural contract (what each routine must reproduce, reference file:line):
+//   frame loop / pixel pack      kernels.cu:320-364        camera ray          Camera.cpp:22-38
+//   primary cast + shadows       kernels.cu:224-318        reflection chain    kernels.cu:130-222
+//   linear object traces         kernels.cu:67-96          model trace         kernels.cu:98-128
+//   sphere / quadratic           Sphere.cpp:17-48, utils.cpp:10-32
+//   plane                        Plane.cpp:16-26           box + box normal    AABB.cpp:36-95
+//   triangle test                Model.cpp:135-159         mesh hit (box gate + all triangles)  Model.cpp:275-317
+//   Phong lighting, hash         kernels.cu:11-65
+//
+// Arithmetic: this file is compiled with -ffp-contract=off and correctly rounded division / square root, and
+// every value that decides a hit or a colour is computed with the reference's operations in the reference's
+// order, so results agree bit for bit with a plain IEEE evaluation on the host (libm calls excepted).  The only
+// approximate arithmetic is the octree child-box slab test (explicit fma + reciprocal), which is conservative:
+// child boxes are padded on the host and the test never rejects a box containing an acceptable triangle.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "rt_device_types.h"
+#include "rt_kernels.h"
+
+namespace rt {
+
+typedef float f4_t __attribute__((ext_vector_type(4)));
+typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
+
+#define RT_DEV __device__ __forceinline__
+#define FAR_T 999.0f
+
+struct V3 { float x, y, z; };
+
+RT_DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
+RT_DEV V3 mk(const float* p) { return mk(p[0], p[1], p[2]); }
+RT_DEV V3 xyz(f4_t v) { return mk(v.x, v.y, v.z); }
+RT_DEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+RT_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+RT_DEV V3 operator*(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+RT_DEV V3 operator*(V3 a, float n) { return mk(a.x * n, a.y * n, a.z * n); }
+RT_DEV V3 operator/(V3 a, float n) { return mk(a.x / n, a.y / n, a.z / n); }
+RT_DEV V3 neg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+RT_DEV float dot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+RT_DEV V3 cross(V3 a, V3 b) { return mk(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x); }
+RT_DEV float length(V3 a) { return sqrtf(a.x * a.x + a.y * a.y + a.z * a.z); }
+RT_DEV V3 normalise(V3 a) { return a / length(a); }
+RT_DEV V3 reflect(V3 a, V3 b) { return a - (b * dot(a, b)) * mk(2.0f, 2.0f, 2.0f); }
+RT_DEV float selMax(float x, float y) { return (x > y) ? x : y; }   // utils.h:91-93
+RT_DEV float selMin(float x, float y) { return (x < y) ? x : y; }   // utils.h:86-88
+
+RT_DEV f4_t ld4(const F4* p) { return *reinterpret_cast<const f4_t*>(p); }
+RT_DEV uint32_t fbits(float f) { return __float_as_uint(f); }
+
+// float -> int, toward zero, saturating, NaN -> 0 (v_cvt_i32_f32 semantics, spelled out).
+RT_DEV int f2iRz(float f) {
+    if (!(f == f)) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+
+// ---------------------------------------------------------------- primitives (exact)
+
+RT_DEV bool solveQuadratic(float a, float b, float c, float& x0, float& x1) {
+    float disc = b * b - 4 * a * c;
+    if (disc < 0) return false;
+    if (disc == 0) {
+        x0 = x1 = (float)(-0.5 * (double)b / (double)a);
+    } else {
+        float q = (b > 0) ? (float)(-0.5 * (double)(b + sqrtf(disc))) : (float)(-0.5 * (double)(b - sqrtf(disc)));
+        x0 = q / a;
+        x1 = c / q;
+    }
+    if (x0 > x1) { float t = x0; x0 = x1; x1 = t; }
+    return true;
+}
+
+RT_DEV bool sphereHit(V3 centre, float radius, V3 o, V3 d, float& t0) {
+    float a0, a1;
+    V3 L = o - centre;
+    float a = dot(d, d);
+    float b = 2 * dot(d, L);
+    float c = dot(L, L) - radius * radius;
+    if (!solveQuadratic(a, b, c, a0, a1)) return false;
+    if (a0 < 0) { a0 = a1; if (a0 < 0) return false; }
+    if (a1 < 0) { a1 = a0; if (a1 < 0) return false; }
+    if (a0 > a1) { float t = a1; a1 = a0; a0 = t; }
+    t0 = a0;
+    return true;
+}
+
+RT_DEV bool planeHit(V3 p, V3 n, V3 o, V3 d, float& t0) {
+    float denom = dot(n, d);
+    V3 v = p - o;
+    t0 = dot(v, n) / denom;
+    return t0 >= 0;
+}
+
+// The reference's slab test, branch for branch (its NaN behaviour decides whether a mesh is tested at all).
+RT_DEV bool boxHit(V3 bmin, V3 bmax, V3 o, V3 d, float& t0) {
+    float tmp;
+    float tmin = (bmin.x - o.x) / d.x, tmax = (bmax.x - o.x) / d.x;
+    if (tmin > tmax) { tmp = tmin; tmin = tmax; tmax = tmp; }
+    float tminY = (bmin.y - o.y) / d.y, tmaxY = (bmax.y - o.y) / d.y;
+    if (tminY > tmaxY) { tmp = tminY; tminY = tmaxY; tmaxY = tmp; }
+    if ((tmin > tmaxY) || (tminY > tmax)) return false;
+    if (tminY > tmin) tmin = tminY;
+    if (tmaxY < tmax) tmax = tmaxY;
+    float tminZ = (bmin.z - o.z) / d.z, tmaxZ = (bmax.z - o.z) / d.z;
+    if (tminZ > tmaxZ) { tmp = tminZ; tminZ = tmaxZ; tmaxZ = tmp; }
+    if ((tmin > tmaxZ) || (tminZ > tmax)) return false;
+    if (tminZ > tmin) tmin = tminZ;
+    if (tmaxZ < tmax) tmax = tmaxZ;
+    if (tmin < 0) { tmin = tmax; if (tmin < 0) return false; }
+    if (tmax < 0) { tmax = tmin; if (tmax < 0) return false; }
+    if (tmin > tmax) { tmp = tmin; tmin = tmax; tmax = tmp; }
+    t0 = tmin;
+    return true;
+}
+
+RT_DEV V3 boxNormalAt(V3 bmin, V3 bmax, V3 point) {
+    V3 centre = (bmin + bmax) / 2.0f;
+    V3 p = point - centre;
+    V3 e = bmin - bmax;
+    V3 h = mk(fabsf(e.x), fabsf(e.y), fabsf(e.z)) / 2.0f;
+    const float bias = 1.00001f;
+    V3 n = mk((float)f2iRz(p.x / h.x * bias), (float)f2iRz(p.y / h.y * bias), (float)f2iRz(p.z / h.z * bias));
+    return normalise(n);
+}
+
+RT_DEV float wangHash(uint32_t seed) {
+    seed = (seed ^ 61u) ^ (seed >> 16);
+    seed *= 9u;
+    seed = seed ^ (seed >> 4);
+    seed *= 0x27d4eb2du;
+    seed = seed ^ (seed >> 15);
+    return (float)seed / 4294967296.0f;
+}
+
+RT_DEV uint32_t sampleSeed(int x, int y, int i) { return ((uint32_t)x * 1000u + (uint32_t)y) * 1973u + (uint32_t)i * 9277u; }
+
+RT_DEV V3 lightSampleOffset(uint32_t seed, float radius) {
+    float theta = 2 * 3.141592654f * wangHash(seed);
+    float phi = acosf(2 * wangHash(seed * 16807u) - 1);
+    return mk(radius * sinf(phi) * cosf(theta), radius * sinf(phi) * sinf(theta), radius * cosf(phi));
+}
+
+// ---------------------------------------------------------------- per-ray working set
+
+struct Mat { V3 ka, kd; float ambient, diffuse, specular, shininess; uint32_t type, flags; };
+
+RT_DEV Mat loadMat(const F4* base, int idx) {
+    f4_t a = ld4(base + 3 * idx), b = ld4(base + 3 * idx + 1), c = ld4(base + 3 * idx + 2);
+    Mat m;
+    m.ka = xyz(a); m.ambient = a.w; m.kd = xyz(b); m.diffuse = b.w;
+    m.specular = c.x; m.shininess = c.y; m.type = fbits(c.z); m.flags = fbits(c.w);
+    return m;
+}
+
+enum { KIND_NONE = -1, KIND_SPHERE = 0, KIND_PLANE = 1, KIND_MODEL = 4, KIND_BOX = 5 };   // utils.h:14-16 values
+
+struct Closest {
+    float t;      // FAR_T = nothing yet
+    int kind, idx;
+    int tri;      // triangle id inside model idx (model hits)
+    float u, v;
+};
+
+struct Counters { uint32_t rays, nodeTests, triTests, attrFetches, gateTests; };
+
+// Per-block traversal stack in LDS: one entry per internal level, [level][thread] so lanes hit distinct banks.
+struct StackRef {
+    uint32_t* base;   // &stackBase[0][tid]
+    uint32_t* mask;
+};
+
+// ---------------------------------------------------------------- octree traversal
+
+// Reorders the 8 child bits so that bit k is child k ^ oct (front-to-back for a ray whose negative axes are oct).
+RT_DEV uint32_t permuteOctants(uint32_t m, uint32_t oct) {
+    if (oct & 1u) m = ((m & 0x55u) << 1) | ((m & 0xAAu) >> 1);
+    if (oct & 2u) m = ((m & 0x33u) << 2) | ((m & 0xCCu) >> 2);
+    if (oct & 4u) m = ((m & 0x0Fu) << 4) | ((m & 0xF0u) >> 4);
+    return m;
+}
+
+RT_DEV float comp(f4_t a, f4_t b, int c) {
+    switch (c) {
+        case 0: return a.x; case 1: return a.y; case 2: return a.z; case 3: return a.w;
+        case 4: return b.x; case 5: return b.y; case 6: return b.z; default: return b.w;
+    }
+}
+
+// Conservative slab test of the eight child boxes of one node.  rd = 1/d (approximate), ord = o * rd.
+// Returns the bit mask of children whose padded box overlaps [0, tmax] along the ray.
+RT_DEV uint32_t testChildren(const F4* node, V3 rd, V3 ord, float tmax) {
+    f4_t lx0 = ld4(node + 0), lx1 = ld4(node + 1), ly0 = ld4(node + 2), ly1 = ld4(node + 3), lz0 = ld4(node + 4), lz1 = ld4(node + 5);
+    f4_t hx0 = ld4(node + 6), hx1 = ld4(node + 7), hy0 = ld4(node + 8), hy1 = ld4(node + 9), hz0 = ld4(node + 10), hz1 = ld4(node + 11);
+    uint32_t mask = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        float ax = __builtin_fmaf(comp(lx0, lx1, c), rd.x, -ord.x), bx = __builtin_fmaf(comp(hx0, hx1, c), rd.x, -ord.x);
+        float ay = __builtin_fmaf(comp(ly0, ly1, c), rd.y, -ord.y), by = __builtin_fmaf(comp(hy0, hy1, c), rd.y, -ord.y);
+        float az = __builtin_fmaf(comp(lz0, lz1, c), rd.z, -ord.z), bz = __builtin_fmaf(comp(hz0, hz1, c), rd.z, -ord.z);
+        // fminf/fmaxf drop a NaN operand (0 * inf on an axis-parallel ray), which keeps the test conservative
+        float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+        float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+        // widen by a few ulps of the larger magnitude: the fma form and the reciprocal are not exact
+        bool hit = tn <= tf + 4e-6f * fmaxf(fabsf(tn), fabsf(tf));
+        mask |= hit ? (1u << c) : 0u;
+    }
+    return mask;
+}
+
+RT_DEV bool tightBoxHit(V3 lo, V3 hi, V3 rd, V3 ord, float tmax) {
+    float ax = __builtin_fmaf(lo.x, rd.x, -ord.x), bx = __builtin_fmaf(hi.x, rd.x, -ord.x);
+    float ay = __builtin_fmaf(lo.y, rd.y, -ord.y), by = __builtin_fmaf(hi.y, rd.y, -ord.y);
+    float az = __builtin_fmaf(lo.z, rd.z, -ord.z), bz = __builtin_fmaf(hi.z, rd.z, -ord.z);
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    return tn <= tf + 4e-6f * fmaxf(fabsf(tn), fabsf(tf));
+}
+
+// Traces (o, d) against every eligible model.
+//   ANYHIT = false: closest hit, merged into `best` with the reference's tie rules (strictly nearer than anything
+//                   found earlier; among triangles of one model the lowest index wins an exact tie).
+//   ANYHIT = true : returns true as soon as some non-debug model has a triangle with 0 < t < 999.
+// skipDebug: models flagged debug are not candidates (reflection and shadow rays).
+template <bool ANYHIT, bool STATS>
+RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug, Closest& best, StackRef stk, Counters& cnt) {
+    const int nMdl = S.nMdl;
+    if (nMdl == 0) return false;
+
+    // approximate reciprocal direction for the child-box tests only
+    V3 rd = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    V3 ord = mk(o.x * rd.x, o.y * rd.y, o.z * rd.z);
+    const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+
+    int m = -1;                 // current model
+    int bestTriInModel = 0x7fffffff;   // id of the current best hit if it lies in model m, else "none"
+    uint32_t base = 0, imask = 0, hits = 0;   // children still to visit below the current node
+    int sp = 0;
+    uint32_t pend = 0;          // leaf children still to intersect (permuted order)
+    uint32_t lr0 = 0, lr1 = 0, lr2 = 0, lr3 = 0, lr4 = 0, lr5 = 0, lr6 = 0, lr7 = 0;
+    bool done = false, found = false;
+
+    for (;;) {
+        // ---- descend until this lane has triangles to test or has run out of models
+        while (!done && pend == 0) {
+            uint32_t node;
+            if (hits != 0) {
+                uint32_t k = __builtin_ctz(hits);
+                hits &= hits - 1;
+                uint32_t c = k ^ oct;
+                node = base + __builtin_popcount(imask & ((1u << c) - 1u));
+            } else if (sp > 0) {
+                sp--;
+                base = stk.base[sp * 256];
+                uint32_t packed = stk.mask[sp * 256];
+                imask = packed & 0xffu;
+                hits = packed >> 8;
+                continue;
+            } else {
+                // next model whose gate the ray passes
+                uint32_t rootRef = kNoRoot;
+                for (;;) {
+                    m++;
+                    if (m >= nMdl) break;
+                    if (skipDebug || ANYHIT) {
+                        uint32_t flags = fbits(S.mdlMat[3 * m + 2].w);
+                        if (flags & 1u) continue;
+                    }
+                    if (STATS) cnt.gateTests++;
+                    float tGate;
+                    if (!boxHit(xyz(ld4(S.mdlGateMin + m)), xyz(ld4(S.mdlGateMax + m)), o, d, tGate)) continue;
+                    float tmax = ANYHIT ? FAR_T : best.t;
+                    if (!tightBoxHit(xyz(ld4(S.mdlTightMin + m)), xyz(ld4(S.mdlTightMax + m)), rd, ord, tmax)) continue;
+                    rootRef = S.mdlInfo[4 * m];
+                    if (rootRef == kNoRoot) continue;
+                    break;
+                }
+                if (m >= nMdl) { done = true; break; }
+                bestTriInModel = 0x7fffffff;
+                if (rootRef & kLeafFlag) { pend = 1u; lr0 = rootRef & ~kLeafFlag; lr1 = lr0; lr2 = lr0; lr3 = lr0; lr4 = lr0; lr5 = lr0; lr6 = lr0; lr7 = lr0; break; }
+                node = rootRef;
+            }
+
+            const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
+            uint32_t hmask = testChildren(np, rd, ord, ANYHIT ? FAR_T : best.t);
+            u4_t meta = *reinterpret_cast<const u4_t*>(np + 14);
+            uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
+            if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
+            if (hits != 0) {   // keep the siblings that are still waiting
+                stk.base[sp * 256] = base;
+                stk.mask[sp * 256] = imask | (hits << 8);
+                sp++;
+            }
+            base = meta.x;
+            imask = nodeImask;
+            hits = permuteOctants(hmask & nodeImask, oct);
+            uint32_t lhit = hmask & nodeLmask;
+            if (lhit) {
+                u4_t ra = *reinterpret_cast<const u4_t*>(np + 12), rb = *reinterpret_cast<const u4_t*>(np + 13);
+                lr0 = ra.x; lr1 = ra.y; lr2 = ra.z; lr3 = ra.w; lr4 = rb.x; lr5 = rb.y; lr6 = rb.z; lr7 = rb.w;
+                pend = permuteOctants(lhit, oct);
+            }
+        }
+        if (pend == 0) break;   // done
+
+        // ---- intersect the triangles of the pending leaves
+        while (pend != 0) {
+            uint32_t k = __builtin_ctz(pend);
+            pend &= pend - 1;
+            uint32_t c = k ^ oct;
+            uint32_t start = c == 0 ? lr0 : c == 1 ? lr1 : c == 2 ? lr2 : c == 3 ? lr3 : c == 4 ? lr4 : c == 5 ? lr5 : c == 6 ? lr6 : lr7;
+            const F4* tp = S.tris + (size_t)start * 3;
+            for (;;) {
+                f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
+                tp += 3;
+                uint32_t idw = fbits(A.w);
+                if (STATS) cnt.triTests++;
+                // Moeller-Trumbore exactly as the reference evaluates it (edges were subtracted on the host)
+                V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
+                V3 pvec = cross(d, e2);
+                float det = dot(e1, pvec);
+                // the reference compares against the double literal -0.01; -0.01f is the smallest float that passes
+                bool rejected = (cull && det >= -0.01f) || (fabsf(det) <= 0);
+                if (!rejected) {
+                    float invDet = 1 / det;
+                    V3 tvec = o - v0;
+                    float u = dot(tvec, pvec) * invDet;
+                    if (!(u < 0 || u > 1)) {
+                        V3 qvec = cross(tvec, e1);
+                        float v = dot(d, qvec) * invDet;
+                        if (!(v < 0 || u + v > 1)) {
+                            float t = dot(e2, qvec) * invDet;
+                            int id = (int)(idw & ~kTriLast);
+                            if (ANYHIT) {
+                                if (t < FAR_T && t > 0) { found = true; }
+                            } else {
+                                if (t > 0 && (t < best.t || (t == best.t && id < bestTriInModel))) {
+                                    best.t = t; best.kind = KIND_MODEL; best.idx = m; best.tri = id; best.u = u; best.v = v;
+                                    bestTriInModel = id;
+                                }
+                            }
+                        }
+                    }
+                }
+                if ((idw & kTriLast) || (ANYHIT && found)) break;
+            }
+            if (ANYHIT && found) { pend = 0; done = true; hits = 0; sp = 0; }
+        }
+        if (ANYHIT && found) break;
+    }
+    return ANYHIT ? found : false;
+}
+
+// ---------------------------------------------------------------- linear object traces
+
+// kernels.cu:67-96 over the three analytic object tables, closest hit.  skipDebug* mirror the ray types the
+// reference uses for each table at this level.
+RT_DEV void traceAnalytic(const DevScene& S, V3 o, V3 d, bool skipDebugSpheres, bool tracePlanes, bool skipDebugPlanes,
+                          bool traceBoxes, Closest& best) {
+    for (int i = 0; i < S.nSph; i++) {
+        f4_t g = ld4(S.sphGeom + i);
+        uint32_t flags = fbits(S.sphMat[3 * i + 2].w);
+        if (flags & 2u) continue;
+        float t0;
+        if (sphereHit(xyz(g), g.w, o, d, t0)) {
+            if (skipDebugSpheres && (flags & 1u)) continue;
+            if (t0 < best.t) { best.t = t0; best.kind = KIND_SPHERE; best.idx = i; }
+        }
+    }
+    if (tracePlanes) {
+        for (int i = 0; i < S.nPln; i++) {
+            uint32_t flags = fbits(S.plnMat[3 * i + 2].w);
+            if (flags & 2u) continue;
+            float t0;
+            if (planeHit(xyz(ld4(S.plnP + i)), xyz(ld4(S.plnN + i)), o, d, t0)) {
+                if (skipDebugPlanes && (flags & 1u)) continue;
+                if (t0 < best.t) { best.t = t0; best.kind = KIND_PLANE; best.idx = i; }
+            }
+        }
+    }
+    if (traceBoxes) {
+        for (int i = 0; i < S.nBox; i++) {
+            float t0;
+            if (boxHit(xyz(ld4(S.boxMin + i)), xyz(ld4(S.boxMax + i)), o, d, t0)) {
+                if (fbits(S.boxMat[3 * i + 2].w) & 1u) continue;   // boxes are always traced as reflection rays (kernels.cu:228)
+                if (t0 < best.t) { best.t = t0; best.kind = KIND_BOX; best.idx = i; }
+            }
+        }
+    }
+}
+
+RT_DEV bool shadowSpheres(const DevScene& S, V3 o, V3 d) {
+    for (int i = 0; i < S.nSph; i++) {
+        f4_t g = ld4(S.sphGeom + i);
+        uint32_t flags = fbits(S.sphMat[3 * i + 2].w);
+        if (flags & 2u) continue;
+        float t0;
+        if (sphereHit(xyz(g), g.w, o, d, t0) && !(flags & 1u)) return true;
+    }
+    return false;
+}
+
+RT_DEV bool shadowBoxes(const DevScene& S, V3 o, V3 d) {
+    for (int i = 0; i < S.nBox; i++) {
+        float t0;
+        if (boxHit(xyz(ld4(S.boxMin + i)), xyz(ld4(S.boxMax + i)), o, d, t0) && !(fbits(S.boxMat[3 * i + 2].w) & 1u)) return true;
+    }
+    return false;
+}
+
+// ---------------------------------------------------------------- shading
+
+RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 eye, V3 normal, const FrameParams& P, int px, int py) {
+    V3 colour = mk(0, 0, 0);
+    V3 L = normalise(lightPos - point);
+    if (P.flags & kCfgAmbient) colour = (lightCol * mat.ka) * mat.ambient;
+    if (P.flags & kCfgDiffuse) {
+        float NdotL = selMax(dot(normal, L), 0.0f);
+        colour = colour + ((NdotL > 0.0f) ? (((mat.kd * lightCol) * mat.diffuse) * NdotL) : mk(0, 0, 0));
+    }
+    if (P.flags & kCfgSpecular) {
+        if (P.flags & kCfgAreaSpecular) {
+            for (int i = 0; i < P.softNum; i++) {
+                V3 ps = lightSampleOffset(sampleSeed(px, py, i), P.softRadius);
+                V3 Ls = normalise((lightPos + ps) - point);
+                V3 v = normalise(eye);
+                V3 r = normalise(neg(reflect(Ls, normal)));
+                float RdotV = selMax(dot(r, v), 0.0f);
+                colour = colour + (lightCol * mat.specular) * powf(RdotV, mat.shininess);
+            }
+        } else {
+            V3 v = normalise(eye);
+            V3 r = normalise(neg(reflect(L, normal)));
+            float RdotV = selMax(dot(r, v), 0.0f);
+            colour = colour + (lightCol * mat.specular) * powf(RdotV, mat.shininess);
+        }
+    }
+    return colour;
+}
+
+// Everything the shader needs about a closest hit.
+struct Surface {
+    Mat mat;
+    V3 point, normal;   // normal as the reference holds it after its trace calls (see normaliseCount)
+};
+
+// Rebuilds hit point, normal and material of `h`.  `renorm` = how many trace routines of the reference run from
+// the winning object's own routine to the last one: each of them normalises the stored normal once more
+// (kernels.cu:90-93, 122-125).
+template <bool STATS>
+RT_DEV Surface resolveSurface(const DevScene& S, V3 o, V3 d, const Closest& h, int renorm, Counters& cnt) {
+    Surface s;
+    s.point = o + d * h.t;
+    if (h.kind == KIND_SPHERE) {
+        s.mat = loadMat(S.sphMat, h.idx);
+        s.normal = s.point - xyz(ld4(S.sphGeom + h.idx));
+    } else if (h.kind == KIND_PLANE) {
+        s.mat = loadMat(S.plnMat, h.idx);
+        s.normal = neg(xyz(ld4(S.plnN + h.idx)));
+    } else if (h.kind == KIND_BOX) {
+        s.mat = loadMat(S.boxMat, h.idx);
+        s.normal = boxNormalAt(xyz(ld4(S.boxMin + h.idx)), xyz(ld4(S.boxMax + h.idx)), s.point);
+    } else {
+        s.mat = loadMat(S.mdlMat, h.idx);
+        uint32_t triBase = S.mdlInfo[4 * h.idx + 1];
+        const F4* ap = S.attrs + (size_t)(triBase + (uint32_t)h.tri) * kAttrFloat4s;
+        f4_t a0 = ld4(ap), a1 = ld4(ap + 1), a2 = ld4(ap + 2), a3 = ld4(ap + 3), a4 = ld4(ap + 4), a5 = ld4(ap + 5), a6 = ld4(ap + 6);
+        if (STATS) cnt.attrFetches++;
+        float u = h.u, v = h.v, w = 1 - u - v;
+        // Model.cpp:300-310: u weights the first vertex, v the second, 1-u-v the third
+        s.normal = (xyz(a0) * u + xyz(a1) * v) + xyz(a2) * w;
+        V3 ka0 = mk(a0.w, a1.w, a2.w), ka1 = xyz(a3), ka2 = xyz(a4);
+        V3 kd0 = mk(a3.w, a4.w, a5.w), kd1 = xyz(a5), kd2 = xyz(a6);
+        s.mat.ka = (ka0 * u + ka1 * v) + ka2 * w;
+        s.mat.kd = (kd0 * u + kd1 * v) + kd2 * w;
+    }
+    for (int i = 0; i < renorm; i++) s.normal = normalise(s.normal);
+    return s;
+}
+
+RT_DEV int renormCount(int kind, bool planesRun, bool boxesRun, bool modelsRun) {
+    if (kind == KIND_MODEL) return 1;
+    const int afterBoxes = modelsRun ? 1 : 0;
+    if (kind == KIND_BOX) return 1 + afterBoxes;
+    const int afterPlanes = (boxesRun ? 1 : 0) + afterBoxes;
+    if (kind == KIND_PLANE) return 1 + afterPlanes;
+    return 1 + (planesRun ? 1 : 0) + afterPlanes;   // sphere
+}
+
+// Hard-shadow test of the primary level: spheres, boxes, models (kernels.cu:268-277); one ray.
+template <bool STATS>
+RT_DEV bool fullShadow(const DevScene& S, const FrameParams& P, V3 so, V3 sd, StackRef stk, Counters& cnt) {
+    if (shadowSpheres(S, so, sd)) return true;
+    if (shadowBoxes(S, so, sd)) return true;
+    if (!(P.flags & kCfgModelsVisible)) return false;
+    Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
+    return traceModels<true, STATS>(S, so, sd, (P.flags & kCfgCull) != 0, true, dummy, stk, cnt);
+}
+
+// One camera sample: kernels.cu:224-318 with the reflection chain kernels.cu:130-222 unrolled into levels.
+template <bool STATS>
+RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px, int py, StackRef stk, Counters& cnt, Closest& primaryOut) {
+    const V3 lightPos = mk(S.lightPos), lightCol = mk(S.lightCol), eye = mk(P.camPos), background = mk(P.background);
+    const bool reflections = (P.flags & kCfgReflections) != 0, reflectPlanes = (P.flags & kCfgReflectPlanes) != 0;
+    const bool boxesRun = (P.flags & kCfgRenderBoxes) != 0, modelsRun = (P.flags & kCfgRenderModels) != 0;
+    const bool modelsVisible = modelsRun && (P.flags & kCfgModelsVisible) != 0;
+    const bool hardShadows = (P.flags & kCfgHardShadows) != 0, cull = (P.flags & kCfgCull) != 0;
+
+    // per level: own colour, how the deeper colour is added, and whether the level is in shadow
+    V3 lvl0 = background, lvl1 = background, lvl2 = background, lvl3 = background;
+    float str0 = 0, str1 = 0, str2 = 0;
+    bool add0 = false, add1 = false, add2 = false, sh0 = false, sh1 = false, sh2 = false, sh3 = false;
+    float softFactor = 1.0f; bool useSoft = false;
+    int deepest = 0;
+
+    V3 ro = o, rdir = d;
+#pragma unroll 1
+    for (int level = 0; level < 4; level++) {
+        deepest = level;
+        cnt.rays++;
+        Closest h; h.t = FAR_T; h.kind = KIND_NONE; h.idx = -1; h.tri = -1; h.u = 0; h.v = 0;
+        const bool planesRun = (level == 0) || reflectPlanes;
+        traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h);
+        if (modelsVisible) {
+            // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
+            traceModels<false, STATS>(S, ro, rdir, cull, (level & 1) != 0, h, stk, cnt);
+        }
+        if (level == 0) primaryOut = h;
+        V3 colour = background;
+        bool next = false;
+        if (h.kind != KIND_NONE) {
+            Surface s = resolveSurface<STATS>(S, ro, rdir, h, renormCount(h.kind, planesRun, boxesRun, modelsRun), cnt);
+            const bool isDebug = (s.mat.flags & 1u) != 0;
+            if (level == 0 && isDebug) {
+                colour = s.mat.ka;                                          // kernels.cu:309-312
+            } else {
+                V3 nLight = (level == 0 && h.kind == KIND_BOX) ? s.normal : normalise(s.normal);   // kernels.cu:240-245
+                colour = lighting(s.mat, lightPos, lightCol, s.point, eye, nLight, P, px, py);
+                V3 biased = s.point + s.normal * P.shadowBias;
+                V3 toLight = normalise(lightPos - s.point);
+                bool wantNext;
+                if (level == 0) wantNext = reflections && s.mat.type == 1u && !(h.kind == KIND_PLANE && !reflectPlanes);
+                else wantNext = reflections && s.mat.type == 1u && (1 < P.maxDepth) && level < 3;
+                float strength = 0; bool add = false;
+                if (wantNext) {
+                    if (h.kind == KIND_PLANE) { strength = P.planeStrength; add = true; }
+                    else if (h.kind == KIND_SPHERE) { strength = P.sphereStrength; add = true; }
+                    else if (h.kind == KIND_MODEL) { strength = P.modelStrength; add = true; }
+                    else if (h.kind == KIND_BOX && level == 0) { strength = P.boxStrength; add = true; }   // kernels.cu:259
+                }
+                bool shadowed = false;
+                if (hardShadows) {
+                    cnt.rays++;
+                    if (level == 0) shadowed = fullShadow<STATS>(S, P, biased, toLight, stk, cnt);
+                    else shadowed = shadowSpheres(S, biased, toLight);                             // kernels.cu:142, 164, 214
+                }
+                if (level == 0 && (P.flags & kCfgSoftShadows)) {                                   // kernels.cu:279-307
+                    int hitsCount = 0;
+                    for (int i = 0; i < P.softNum; i++) {
+                        V3 ps = lightSampleOffset(sampleSeed(px, py, i), P.softRadius);
+                        V3 lightPoint = lightPos + ps;
+                        V3 sd = normalise(lightPoint - s.point);
+                        cnt.rays++;
+                        hitsCount += shadowSpheres(S, biased, sd) ? 1 : 0;
+                        hitsCount += shadowBoxes(S, biased, sd) ? 1 : 0;
+                        if (P.flags & kCfgModelsVisible) {   // the shadow traces ignore renderModels (kernels.cu:304)
+                            Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
+                            hitsCount += traceModels<true, STATS>(S, biased, sd, cull, true, dummy, stk, cnt) ? 1 : 0;
+                        }
+                    }
+                    softFactor = 1 - ((float)hitsCount / (float)P.softNum);
+                    useSoft = true;
+                }
+                if (level == 0) { str0 = strength; add0 = add; sh0 = shadowed; }
+                else if (level == 1) { str1 = strength; add1 = add; sh1 = shadowed; }
+                else if (level == 2) { str2 = strength; add2 = add; sh2 = shadowed; }
+                else { sh3 = shadowed; }
+                if (wantNext) {
+                    next = true;
+                    V3 r = normalise(reflect(rdir, s.normal));
+                    ro = biased;
+                    rdir = r;
+                }
+            }
+        }
+        if (level == 0) lvl0 = colour; else if (level == 1) lvl1 = colour; else if (level == 2) lvl2 = colour; else lvl3 = colour;
+        if (!next) break;
+    }
+
+    // fold the levels back together in the reference's order of operations
+    V3 c3 = lvl3;
+    if (sh3) c3 = c3 * P.shadowIntensity;                               // kernels.cu:140-144
+    V3 c2 = lvl2;
+    if (sh2) c2 = c2 * P.shadowIntensity;                               // kernels.cu:162-166 (before the add)
+    if (deepest >= 3 && add2) c2 = c2 + c3 * str2;                      // kernels.cu:168-180
+    V3 c1 = lvl1;
+    if (deepest >= 2 && add1) c1 = c1 + c2 * str1;                      // kernels.cu:198-210
+    if (sh1) c1 = c1 * P.shadowIntensity;                               // kernels.cu:212-216 (after the add)
+    V3 c0 = lvl0;
+    if (deepest >= 1 && add0) c0 = c0 + c1 * str0;                      // kernels.cu:248-266
+    if (sh0) c0 = c0 * P.shadowIntensity;                               // kernels.cu:268-277
+    if (useSoft) c0 = c0 * softFactor;                                  // kernels.cu:306
+    return c0;
+}
+
+RT_DEV V3 rasterToCameraSpace(const FrameParams& P, float x, float y) {
+    float ndcx = x / (float)P.width, ndcy = y / (float)P.height;
+    float sx = 2 * ndcx - 1, sy = 1 - 2 * ndcy;
+    float cx = sx * 1 * P.fovFactor, cy = sy * P.fovFactor, cz = 1;
+    return (mk(P.camRight) * cx + mk(P.camUp) * cy) + mk(P.camDir) * cz;
+}
+
+RT_DEV uint8_t packChannel(float c) {
+    float v = selMin(c, 1.0f) * 255;
+    if (!(v > 0)) return 0;
+    return (uint8_t)f2iRz(v);
+}
+
+// Block b of the launch -> which 16x16 pixel block of which owned tile.  Consecutive workgroups go to different
+// XCDs, so the id is remapped to give each XCD (own L2) a contiguous run of screen blocks.
+RT_DEV uint32_t xcdRemap(uint32_t b, uint32_t n) {
+    const uint32_t q = n / 8u, r = n % 8u, xcd = b % 8u, i = b / 8u;
+    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + i;
+}
+
+template <bool STATS>
+__global__ __launch_bounds__(256) void renderKernel(DevScene S, FrameParams P, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
+                                                    float* __restrict__ tbuf, unsigned long long* __restrict__ counters) {
+    __shared__ uint32_t stackBase[kMaxOctreeDepth * 256];
+    __shared__ uint32_t stackMask[kMaxOctreeDepth * 256];
+    const uint32_t tid = threadIdx.x;
+    StackRef stk; stk.base = stackBase + tid; stk.mask = stackMask + tid;
+
+    constexpr int kBlocksPerTileSide = RT_TILE_PX / 16;                     // 16x16 pixel blocks along a tile edge
+    constexpr int kBlocksPerTile = kBlocksPerTileSide * kBlocksPerTileSide;
+    const uint32_t b = xcdRemap(blockIdx.x, gridDim.x);
+    const uint32_t localTile = b / kBlocksPerTile, inTile = b % kBlocksPerTile;
+    const uint32_t tile = localTile * (uint32_t)P.world + (uint32_t)P.rank;
+    const uint32_t tileX = tile % (uint32_t)P.tilesX, tileY = tile / (uint32_t)P.tilesX;
+    // wave w of the block owns the 8x8 quadrant (w & 1, w >> 1); lane l is pixel (l & 7, l >> 3) of it
+    const uint32_t wave = tid >> 6, lane = tid & 63u;
+    const uint32_t bx = inTile % kBlocksPerTileSide, by = inTile / kBlocksPerTileSide;
+    const uint32_t lx = bx * 16u + (wave & 1u) * 8u + (lane & 7u), ly = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
+
+    Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0;
+    if (x < P.width && y < P.height) {
+        const V3 camPos = mk(P.camPos);
+        V3 col;
+        Closest primary; primary.t = FAR_T; primary.kind = KIND_NONE; primary.idx = -1; primary.tri = -1; primary.u = 0; primary.v = 0;
+        if (P.flags & kCfgAntiAlias) {                                      // kernels.cu:331-341
+            V3 total = mk(0, 0, 0);
+            bool first = true;
+            for (float i = 0.25f; i <= 0.75f; i += 0.5f) {
+                for (float j = 0.25f; j <= 0.75f; j += 0.5f) {
+                    V3 p = rasterToCameraSpace(P, (float)x + i, (float)y + j);
+                    Closest ph;
+                    total = total + castSample<STATS>(S, P, camPos, normalise(p), x, y, stk, cnt, ph);
+                    if (first) { primary = ph; first = false; }
+                }
+            }
+            col = total / 4.0f;
+        } else {                                                            // kernels.cu:353-357
+            V3 p = rasterToCameraSpace(P, (float)((double)x + 0.5), (float)((double)y + 0.5));
+            col = castSample<STATS>(S, P, camPos, normalise(p), x, y, stk, cnt, primary);
+        }
+        size_t pix;
+        if (P.compactOutput) pix = (size_t)localTile * (RT_TILE_PX * RT_TILE_PX) + (size_t)ly * RT_TILE_PX + lx;
+        else pix = (size_t)y * (size_t)P.width + (size_t)x;
+        out[pix * 3 + 0] = packChannel(col.x);
+        out[pix * 3 + 1] = packChannel(col.y);
+        out[pix * 3 + 2] = packChannel(col.z);
+        if (ids) {
+            size_t fp = (size_t)y * (size_t)P.width + (size_t)x;
+            bool hit = primary.kind != KIND_NONE;
+            ids[fp * 2 + 0] = hit ? ((primary.kind << 24) | (primary.idx & 0xFFFFFF)) : -1;
+            ids[fp * 2 + 1] = hit ? primary.tri : -1;
+            if (tbuf) tbuf[fp] = primary.t;
+        } else if (tbuf) {
+            tbuf[(size_t)y * (size_t)P.width + (size_t)x] = primary.t;
+        }
+    }
+
+    // one atomic per wave and counter
+    if (counters) {
+        uint32_t vals[kCntCount] = {cnt.rays, cnt.nodeTests, cnt.triTests, cnt.attrFetches, cnt.gateTests};
+#pragma unroll
+        for (int c = 0; c < kCntCount; c++) {
+            if (!STATS && c != kCntRays) continue;
+            uint32_t v = vals[c];
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+            if (lane == 0 && v) atomicAdd(&counters[c], (unsigned long long)v);
+        }
+    }
+}
+
+// Tile-major buffers of `world` ranks laid end to end -> row-major frame.  One thread per 4 output bytes.
+__global__ __launch_bounds__(256) void untileKernel(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ out, int width, int height,
+                                                    int world, int tilesX, size_t perRankBytes) {
+    const size_t total = (size_t)width * (size_t)height * 3;
+    const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+    if (i4 >= total) return;
+    uint8_t v[4];
+    for (int k = 0; k < 4; k++) {
+        size_t i = i4 + k;
+        if (i >= total) { v[k] = 0; continue; }
+        size_t pix = i / 3; int ch = (int)(i % 3);
+        int x = (int)(pix % (size_t)width), y = (int)(pix / (size_t)width);
+        int tile = (y / RT_TILE_PX) * tilesX + (x / RT_TILE_PX);
+        int rank = tile % world, local = tile / world;
+        size_t src = (size_t)rank * perRankBytes + ((size_t)local * (RT_TILE_PX * RT_TILE_PX) + (size_t)(y % RT_TILE_PX) * RT_TILE_PX + (x % RT_TILE_PX)) * 3 + ch;
+        v[k] = gathered[src];
+    }
+    if (i4 + 4 <= total) {
+        *reinterpret_cast<uint32_t*>(out + i4) = (uint32_t)v[0] | ((uint32_t)v[1] << 8) | ((uint32_t)v[2] << 16) | ((uint32_t)v[3] << 24);
+    } else {
+        for (int k = 0; k < 4 && i4 + k < total; k++) out[i4 + k] = v[k];
+    }
+}
+
+// ---------------------------------------------------------------- launch wrappers (host)
+
+hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
+                        unsigned long long* counters, bool stats, hipStream_t stream) {
+    if (P.ownedTiles <= 0) return hipSuccess;
+    constexpr int kBlocksPerTile = (RT_TILE_PX / 16) * (RT_TILE_PX / 16);
+    dim3 grid((unsigned)(P.ownedTiles * kBlocksPerTile)), block(256);
+    if (stats) hipLaunchKernelGGL(renderKernel<true>, grid, block, 0, stream, S, P, out, ids, tbuf, counters);
+    else hipLaunchKernelGGL(renderKernel<false>, grid, block, 0, stream, S, P, out, ids, tbuf, counters);
+    return hipGetLastError();
+}
+
+hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX, size_t perRankBytes,
+                        hipStream_t stream) {
+    size_t total = (size_t)width * (size_t)height * 3;
+    size_t threads = (total + 3) / 4;
+    dim3 grid((unsigned)((threads + 255) / 256)), block(256);
+    hipLaunchKernelGGL(untileKernel, grid, block, 0, stream, gathered, out, width, height, world, tilesX, perRankBytes);
+    return hipGetLastError();
+}
+
+}  // namespace rt

@@ -1,0 +1,309 @@
+// Scene flattening and octree construction (host).
+//
+// Replaces the reference's pointer-linked managed-memory octree (Octree.cpp:11-43, OctreeNode.cpp:3-14), which is
+// never built nor traversed there, by a spatial octree that is emitted directly as the flat 256-byte node array
+// the kernels read.  The octree is only an accelerator: a mesh hit is defined by the reference's whole-model box
+// gate plus its linear triangle loop (Model.cpp:275-317), and the traversal kernel reproduces exactly that result.
+#include "rt_scene.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+
+namespace rt {
+
+namespace {
+
+
+inline float bitsFloat(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline F4 f4(float x, float y, float z, float w) { return F4{x, y, z, w}; }
+inline F4 f4(const rt_vec3& v, float w) { return F4{v.x, v.y, v.z, w}; }
+inline bool finite3(const rt_vec3& v) { return std::isfinite(v.x) && std::isfinite(v.y) && std::isfinite(v.z); }
+
+struct Box {
+    float lo[3] = {std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity(), std::numeric_limits<float>::infinity()};
+    float hi[3] = {-std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity(), -std::numeric_limits<float>::infinity()};
+    void grow(const float p[3]) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], p[a]); hi[a] = std::max(hi[a], p[a]); } }
+    void grow(const Box& b) { for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], b.lo[a]); hi[a] = std::max(hi[a], b.hi[a]); } }
+};
+
+// Triangle as the builder sees it.
+struct BuildTri {
+    Box box;
+    float centre[3];
+};
+
+// Temporary pointer tree; flattened breadth-first afterwards so that siblings are contiguous.
+struct TreeNode {
+    Box box;
+    int child[8];
+    int first = 0, count = 0;   // leaf: slice of the permutation array
+    bool leaf = true;
+};
+
+class OctreeBuilder {
+public:
+    OctreeBuilder(const std::vector<BuildTri>& tris, const OctreeParams& p) : tris_(tris), params_(p) {
+        perm_.resize(tris.size());
+        for (size_t i = 0; i < tris.size(); i++) perm_[i] = (int)i;
+        scratch_.resize(tris.size());
+    }
+
+    int build() { return tris_.empty() ? -1 : buildRange(0, (int)tris_.size(), 0); }
+
+    std::vector<TreeNode> nodes;
+    std::vector<int> perm_;
+    int deepest = 0;
+
+private:
+    int buildRange(int first, int count, int depth) {
+        int self = (int)nodes.size();
+        nodes.emplace_back();
+        {
+            TreeNode& n = nodes[self];
+            for (int c = 0; c < 8; c++) n.child[c] = -1;
+            n.first = first; n.count = count;
+            for (int i = 0; i < count; i++) n.box.grow(tris_[perm_[first + i]].box);
+        }
+        deepest = std::max(deepest, depth);
+        if (count <= params_.leafTriangles || depth >= params_.maxDepth) return self;
+
+        // Split point: middle of the triangles' centre bounds.
+        Box cb;
+        for (int i = 0; i < count; i++) cb.grow(tris_[perm_[first + i]].centre);
+        float mid[3];
+        for (int a = 0; a < 3; a++) mid[a] = 0.5f * cb.lo[a] + 0.5f * cb.hi[a];
+
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < count; i++) cnt[octant(tris_[perm_[first + i]].centre, mid)]++;
+        int biggest = *std::max_element(cnt, cnt + 8);
+        if (biggest == count) return self;   // all centres on one side of every plane: cannot be split further
+
+        int off[8], pos[8];
+        off[0] = 0;
+        for (int c = 1; c < 8; c++) off[c] = off[c - 1] + cnt[c - 1];
+        std::memcpy(pos, off, sizeof pos);
+        for (int i = 0; i < count; i++) {
+            int t = perm_[first + i];
+            scratch_[first + pos[octant(tris_[t].centre, mid)]++] = t;
+        }
+        std::copy(scratch_.begin() + first, scratch_.begin() + first + count, perm_.begin() + first);
+
+        nodes[self].leaf = false;
+        for (int c = 0; c < 8; c++) {
+            if (cnt[c] == 0) continue;
+            int childIdx = buildRange(first + off[c], cnt[c], depth + 1);
+            nodes[self].child[c] = childIdx;
+        }
+        return self;
+    }
+
+    static int octant(const float c[3], const float mid[3]) {
+        return (c[0] > mid[0] ? 1 : 0) | (c[1] > mid[1] ? 2 : 0) | (c[2] > mid[2] ? 4 : 0);
+    }
+
+    const std::vector<BuildTri>& tris_;
+    OctreeParams params_;
+    std::vector<int> scratch_;
+};
+
+}  // namespace
+
+int64_t reachableTriangles(int64_t indicesCount) {
+    if (indicesCount <= 3) return 0;
+    return (indicesCount - 3 + 2) / 3;
+}
+
+void packMaterial(const rt_material& m, int objectType, uint32_t flags, F4 out[3]) {
+    out[0] = f4(m.ambientColour, m.ambient);
+    out[1] = f4(m.diffuseColour, m.diffuse);
+    out[2] = f4(m.specular, m.shininess, bitsFloat((uint32_t)objectType), bitsFloat(flags));
+}
+
+static bool isIgnoredPosition(const rt_vec3& p) { return p.x == -999.0f && p.y == -999.0f && p.z == -999.0f; }
+
+// Emits the octree and triangle records of one model into the shared arrays.
+static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& params, FlatScene& out, std::string& err) {
+    const int64_t nTri = reachableTriangles(m.indicesCount);
+    const uint32_t triBase = (uint32_t)(out.attrs.size() / kAttrFloat4s);
+
+    if (nTri > 0 && (!m.vertices || !m.indices)) { err = "model " + std::to_string(modelIndex) + ": null vertex or index array"; return false; }
+    if (nTri >= (int64_t)kTriLast) { err = "model " + std::to_string(modelIndex) + ": too many triangles"; return false; }
+
+    std::vector<BuildTri> btris((size_t)nTri);
+    Box tight;
+    float maxAbs = 0.0f;
+    for (int64_t t = 0; t < nTri; t++) {
+        const int32_t* ix = m.indices + 3 * t;
+        for (int k = 0; k < 3; k++) {
+            if (ix[k] < 0 || ix[k] >= m.vertCount) { err = "model " + std::to_string(modelIndex) + ": index out of range"; return false; }
+        }
+        const rt_vertex& a = m.vertices[ix[0]];
+        const rt_vertex& b = m.vertices[ix[1]];
+        const rt_vertex& c = m.vertices[ix[2]];
+        if (!finite3(a.position) || !finite3(b.position) || !finite3(c.position)) {
+            err = "model " + std::to_string(modelIndex) + ": non-finite vertex position"; return false;
+        }
+        BuildTri& bt = btris[(size_t)t];
+        const float pa[3] = {a.position.x, a.position.y, a.position.z};
+        const float pb[3] = {b.position.x, b.position.y, b.position.z};
+        const float pc[3] = {c.position.x, c.position.y, c.position.z};
+        bt.box.grow(pa); bt.box.grow(pb); bt.box.grow(pc);
+        for (int ax = 0; ax < 3; ax++) {
+            bt.centre[ax] = 0.5f * bt.box.lo[ax] + 0.5f * bt.box.hi[ax];
+            maxAbs = std::max(maxAbs, std::max(std::fabs(bt.box.lo[ax]), std::fabs(bt.box.hi[ax])));
+        }
+        tight.grow(bt.box);
+
+        // shading attributes, original triangle order
+        F4 rec[kAttrFloat4s];
+        rec[0] = f4(a.normal, a.ambient.x);
+        rec[1] = f4(b.normal, a.ambient.y);
+        rec[2] = f4(c.normal, a.ambient.z);
+        rec[3] = f4(b.ambient, a.diffuse.x);
+        rec[4] = f4(c.ambient, a.diffuse.y);
+        rec[5] = f4(b.diffuse, a.diffuse.z);
+        rec[6] = f4(c.diffuse, 0.0f);
+        out.attrs.insert(out.attrs.end(), rec, rec + kAttrFloat4s);
+    }
+
+    // Child boxes are padded so that the approximate slab test of the traversal can never reject a box whose
+    // triangle the exact intersection routine would accept.
+    const float pad = std::max(1e-3f, 4e-6f * maxAbs);
+
+    OctreeBuilder builder(btris, params);
+    int root = builder.build();
+
+    auto emitLeaf = [&](const TreeNode& n) -> uint32_t {
+        uint32_t start = (uint32_t)(out.tris.size() / 3);
+        std::vector<int> ids(builder.perm_.begin() + n.first, builder.perm_.begin() + n.first + n.count);
+        std::sort(ids.begin(), ids.end());
+        for (size_t i = 0; i < ids.size(); i++) {
+            const int32_t* ix = m.indices + 3 * (int64_t)ids[i];
+            const rt_vec3& p0 = m.vertices[ix[0]].position;
+            const rt_vec3& p1 = m.vertices[ix[1]].position;
+            const rt_vec3& p2 = m.vertices[ix[2]].position;
+            uint32_t id = (uint32_t)ids[i] | (i + 1 == ids.size() ? kTriLast : 0u);
+            out.tris.push_back(f4(p0.x, p0.y, p0.z, bitsFloat(id)));
+            out.tris.push_back(f4(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, 0.0f));   // Model.cpp:137
+            out.tris.push_back(f4(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z, 0.0f));   // Model.cpp:138
+        }
+        out.leafCount++;
+        return start;
+    };
+
+    uint32_t rootRef = kNoRoot;
+    if (root >= 0) {
+        const std::vector<TreeNode>& T = builder.nodes;
+        if (T[root].leaf) {
+            rootRef = kLeafFlag | emitLeaf(T[root]);
+        } else {
+            // breadth-first flattening: (tree node, flat node index)
+            std::vector<std::pair<int, uint32_t>> queue;
+            uint32_t flatRoot = (uint32_t)(out.nodes.size() / kNodeFloat4s);
+            out.nodes.resize(out.nodes.size() + kNodeFloat4s);
+            queue.emplace_back(root, flatRoot);
+            rootRef = flatRoot;
+            const float inf = std::numeric_limits<float>::infinity();
+            for (size_t q = 0; q < queue.size(); q++) {
+                const TreeNode& n = T[queue[q].first];
+                const uint32_t self = queue[q].second;
+                float lo[3][8], hi[3][8];
+                uint32_t leafRef[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                uint32_t imask = 0, lmask = 0;
+                uint32_t childBase = (uint32_t)(out.nodes.size() / kNodeFloat4s);
+                int internalChildren = 0;
+                for (int c = 0; c < 8; c++) {
+                    if (n.child[c] >= 0 && !T[n.child[c]].leaf) internalChildren++;
+                }
+                out.nodes.resize(out.nodes.size() + (size_t)internalChildren * kNodeFloat4s);
+                uint32_t next = childBase;
+                for (int c = 0; c < 8; c++) {
+                    for (int a = 0; a < 3; a++) { lo[a][c] = inf; hi[a][c] = -inf; }
+                    if (n.child[c] < 0) continue;
+                    const TreeNode& ch = T[n.child[c]];
+                    for (int a = 0; a < 3; a++) { lo[a][c] = ch.box.lo[a] - pad; hi[a][c] = ch.box.hi[a] + pad; }
+                    if (ch.leaf) { lmask |= 1u << c; leafRef[c] = emitLeaf(ch); }
+                    else { imask |= 1u << c; queue.emplace_back(n.child[c], next++); }
+                }
+                F4* rec = &out.nodes[(size_t)self * kNodeFloat4s];
+                for (int a = 0; a < 3; a++) {
+                    rec[2 * a + 0] = f4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+                    rec[2 * a + 1] = f4(lo[a][4], lo[a][5], lo[a][6], lo[a][7]);
+                    rec[6 + 2 * a + 0] = f4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+                    rec[6 + 2 * a + 1] = f4(hi[a][4], hi[a][5], hi[a][6], hi[a][7]);
+                }
+                rec[12] = f4(bitsFloat(leafRef[0]), bitsFloat(leafRef[1]), bitsFloat(leafRef[2]), bitsFloat(leafRef[3]));
+                rec[13] = f4(bitsFloat(leafRef[4]), bitsFloat(leafRef[5]), bitsFloat(leafRef[6]), bitsFloat(leafRef[7]));
+                rec[14] = f4(bitsFloat(childBase), bitsFloat(imask | (lmask << 8)), 0.0f, 0.0f);
+                rec[15] = f4(0.0f, 0.0f, 0.0f, 0.0f);
+            }
+        }
+        out.maxDepth = std::max(out.maxDepth, builder.deepest);
+    }
+
+    F4 mat[3];
+    packMaterial(m.mat, m.objectType, m.debug ? 1u : 0u, mat);
+    out.mdlMat.insert(out.mdlMat.end(), mat, mat + 3);
+    out.mdlGateMin.push_back(f4(m.bbMin, 0.0f));
+    out.mdlGateMax.push_back(f4(m.bbMax, 0.0f));
+    if (nTri > 0) {
+        out.mdlTightMin.push_back(f4(tight.lo[0] - pad, tight.lo[1] - pad, tight.lo[2] - pad, 0.0f));
+        out.mdlTightMax.push_back(f4(tight.hi[0] + pad, tight.hi[1] + pad, tight.hi[2] + pad, 0.0f));
+    } else {
+        const float inf = std::numeric_limits<float>::infinity();
+        out.mdlTightMin.push_back(f4(inf, inf, inf, 0.0f));
+        out.mdlTightMax.push_back(f4(-inf, -inf, -inf, 0.0f));
+    }
+    out.mdlInfo.push_back(rootRef);
+    out.mdlInfo.push_back(triBase);
+    out.mdlInfo.push_back(0);
+    out.mdlInfo.push_back(0);
+    out.triangleCount += nTri;
+    return true;
+}
+
+bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err) {
+    out = FlatScene();
+    if (s.sphereCount < 0 || s.planeCount < 0 || s.AABBCount < 0 || s.modelCount < 0) { err = "negative object count"; return false; }
+    if (s.lightCount < 1 || !s.lights) { err = "scene needs at least one light (lights[0] is the only one read)"; return false; }
+    if ((s.sphereCount && !s.spheres) || (s.planeCount && !s.planes) || (s.AABBCount && !s.AABBs) || (s.modelCount && !s.models)) {
+        err = "null object array with non-zero count"; return false;
+    }
+    OctreeParams params;
+    if (s.octreeMaxDepth > 0) params.maxDepth = s.octreeMaxDepth;
+    if (s.octreeLeafTriangles > 0) params.leafTriangles = s.octreeLeafTriangles;
+    if (params.maxDepth > kMaxOctreeDepth) { err = "octreeMaxDepth exceeds " + std::to_string(kMaxOctreeDepth); return false; }
+
+    F4 mat[3];
+    for (int i = 0; i < s.sphereCount; i++) {
+        const rt_sphere& o = s.spheres[i];
+        out.sphGeom.push_back(f4(o.position, o.radius));
+        packMaterial(o.mat, o.objectType, (o.debug ? 1u : 0u) | (isIgnoredPosition(o.position) ? 2u : 0u), mat);
+        out.sphMat.insert(out.sphMat.end(), mat, mat + 3);
+    }
+    for (int i = 0; i < s.planeCount; i++) {
+        const rt_plane& o = s.planes[i];
+        out.plnP.push_back(f4(o.position, 0.0f));
+        out.plnN.push_back(f4(o.n, 0.0f));
+        packMaterial(o.mat, o.objectType, (o.debug ? 1u : 0u) | (isIgnoredPosition(o.position) ? 2u : 0u), mat);
+        out.plnMat.insert(out.plnMat.end(), mat, mat + 3);
+    }
+    for (int i = 0; i < s.AABBCount; i++) {
+        const rt_aabb& o = s.AABBs[i];
+        out.boxMin.push_back(f4(o.min, 0.0f));
+        out.boxMax.push_back(f4(o.max, 0.0f));
+        packMaterial(o.mat, o.objectType, o.debug ? 1u : 0u, mat);
+        out.boxMat.insert(out.boxMat.end(), mat, mat + 3);
+    }
+    for (int i = 0; i < s.modelCount; i++) {
+        if (!flattenModel(s.models[i], i, params, out, err)) return false;
+    }
+    out.nodeCount = (int64_t)(out.nodes.size() / kNodeFloat4s);
+    out.lightPos[0] = s.lights[0].position.x; out.lightPos[1] = s.lights[0].position.y; out.lightPos[2] = s.lights[0].position.z;
+    out.lightCol[0] = s.lights[0].colour.x; out.lightCol[1] = s.lights[0].colour.y; out.lightCol[2] = s.lights[0].colour.z;
+    return true;
+}
+
+}  // namespace rt

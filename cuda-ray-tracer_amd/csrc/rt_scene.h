@@ -1,0 +1,38 @@
+// Host-side flattening of an rt_scene_desc into the device layout of rt_device_types.h.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rt_device_types.h"
+#include "rt_types.h"
+
+namespace rt {
+
+struct OctreeParams {
+    int maxDepth = 8;        // levels of internal nodes
+    int leafTriangles = 4;   // a node with at most this many triangles is a leaf
+};
+
+// Host staging copy of everything that goes to HBM.
+struct FlatScene {
+    std::vector<F4> sphGeom, sphMat, plnP, plnN, plnMat, boxMin, boxMax, boxMat;
+    std::vector<F4> mdlGateMin, mdlGateMax, mdlTightMin, mdlTightMax, mdlMat;
+    std::vector<uint32_t> mdlInfo;
+    std::vector<F4> nodes, tris, attrs;
+    float lightPos[3] = {0, 0, 0}, lightCol[3] = {0, 0, 0};
+    int64_t triangleCount = 0, nodeCount = 0, leafCount = 0;
+    int maxDepth = 0;
+};
+
+// Number of triangles the reference's loops visit for a model with this many indices
+// (for (i = 0; i < indicesCount - 3; i += 3), Model.cpp:282): the last triangle is never reached.
+int64_t reachableTriangles(int64_t indicesCount);
+
+// Fills `out` from `scene`.  Returns false and sets `err` if the scene fails validation.
+bool flattenScene(const rt_scene_desc& scene, FlatScene& out, std::string& err);
+
+// Packs one material into the three-float4 device form.
+void packMaterial(const rt_material& m, int objectType, uint32_t flags, F4 out[3]);
+
+}  // namespace rt

@@ -1,0 +1,147 @@
+/*
+ * rt_api.h — C ABI of the MI355X (gfx950) renderer.
+ *
+ * This is the drop-in boundary for the reference's render path: the sole
+ * caller of the reference kernel is RayTracer::launchKernel()
+ * (RayTracer.cpp:405-417), which launches kernels.h:11 `rayTrace` and then
+ * synchronises.  A host application keeps its Scene / SceneConfig / Camera
+ * objects, mirrors them into the plain structs of rt_types.h, and calls the
+ * functions below instead of launching the kernel itself.
+ *
+ * Conventions
+ *  - every function returns 0 on success and a non-zero rt_status otherwise;
+ *    rt_last_error() then returns a message for the calling thread.  (The
+ *    reference only prints cudaGetErrorString to stderr and carries on,
+ *    RayTracer.cpp:411-414.)
+ *  - inputs are caller-owned and only read during the call; device memory is
+ *    owned by the context.
+ *  - a context is not re-entrant: one thread at a time per rt_ctx, exactly as
+ *    the reference's single GLFW thread drives one RayTracer.
+ *  - host-pointer entry points block until the frame is complete (the
+ *    reference's cudaDeviceSynchronize, RayTracer.cpp:416); *_device entry
+ *    points enqueue on the given HIP stream and return.
+ */
+#ifndef RT_API_H
+#define RT_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_ctx rt_ctx;
+
+enum rt_status {
+    RT_OK = 0,
+    RT_ERR_INVALID = 1,     /* bad argument / scene fails validation */
+    RT_ERR_DEVICE = 2,      /* HIP runtime error */
+    RT_ERR_NO_SCENE = 3,    /* render requested before rt_upload_scene */
+    RT_ERR_NO_STATE = 4,    /* render requested before rt_update_frame_state */
+    RT_ERR_CAPACITY = 5     /* caller buffer too small */
+};
+
+/* Image tiles used to shard a frame over GPUs: RT_TILE x RT_TILE pixels, tile i belongs to rank i % world. */
+#define RT_TILE 64
+
+/*
+ * Creates a context on HIP device devices[0] (device_count must be 1: one process drives one GPU; a frame
+ * is sharded over several GPUs by giving each process its own context and rank, see rt_render_tiles_device).
+ * Replaces the device-side set-up in RayTracer::init / initialiseScenes (RayTracer.cpp:58-69, 342-351);
+ * the curand state buffer of the reference (RayTracer.cpp:344-345, kernels.cu:366-369) is never consumed
+ * by its kernel and has no counterpart here.
+ */
+int rt_create(int device_count, const int* devices, rt_ctx** out);
+
+/* Frees every device allocation of the context.  Replaces RayTracer::~RayTracer (RayTracer.cpp:18-56). */
+void rt_destroy(rt_ctx* ctx);
+
+/*
+ * Flattens a host scene into device-resident SoA buffers and builds the per-model octrees.
+ * Replaces the managed-memory scene arrays filled by RayTracer::initialiseScenes (RayTracer.cpp:71-337),
+ * RayTracer::switchScene (RayTracer.cpp:356-358), addSphere/addPlane/addAABB (RayTracer.cpp:360-403) and the
+ * upload half of Model::Model (Model.cpp:55-56, 70-117).  Call again whenever objects are added or replaced.
+ */
+int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene);
+
+/*
+ * Sets what the reference passes by value on every launch (Scene::cam and SceneConfig, kernels.h:11) plus the
+ * scene members its frame loop rewrites between launches (Window.cpp:357-384).  dyn may be NULL.
+ */
+int rt_update_frame_state(rt_ctx* ctx, const rt_camera* cam, const rt_config* config, const rt_dynamic* dyn);
+
+/*
+ * Renders one width x height frame and copies it to rgb_out (host, 3*width*height bytes, row-major, RGB8).
+ * Replaces RayTracer::launchKernel (RayTracer.cpp:405-417) plus the host read of the managed framebuffer
+ * (Window.cpp:414).  stats may be NULL.
+ */
+int rt_render_frame(rt_ctx* ctx, int width, int height, uint8_t* rgb_out, rt_frame_stats* stats);
+
+/*
+ * As rt_render_frame, and also returns per-pixel primary-hit identities: ids_out holds two int32 per pixel,
+ * (objectName << 24 | object index, triangle index within the model) or (-1, -1) for a miss; t_out the
+ * primary hit distance (999 = miss).  Either may be NULL.  The reference keeps no such buffers; they exist
+ * so that hit parity can be checked.  The launch also fills the traversal counters of rt_frame_stats.
+ */
+int rt_render_frame_ids(rt_ctx* ctx, int width, int height, uint8_t* rgb_out, int32_t* ids_out, float* t_out,
+                        rt_frame_stats* stats);
+
+/*
+ * Enqueues one frame on hip_stream (a hipStream_t, NULL = default stream) writing RGB8 to the device buffer
+ * d_rgb (3*width*height bytes).  The kernels.h:11 launch without the synchronise.  Allocates nothing.
+ */
+int rt_render_device(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_stream);
+
+/* Bytes one rank must provide to rt_render_tiles_device for a width x height frame split over `world` ranks. */
+size_t rt_tile_buffer_bytes(int width, int height, int world);
+
+/*
+ * Renders only the RT_TILE x RT_TILE tiles owned by `rank` (tile i, row-major over the tile grid, belongs to
+ * rank i % world) into d_tiles, compactly: the rank's j-th tile occupies bytes [j*3*RT_TILE^2, (j+1)*3*RT_TILE^2),
+ * row-major inside the tile, edge tiles padded.  No reference counterpart (the reference is single-GPU).
+ */
+int rt_render_tiles_device(rt_ctx* ctx, int width, int height, int rank, int world, void* d_tiles,
+                           size_t capacity_bytes, void* hip_stream);
+
+/*
+ * Reassembles a frame from `world` tile buffers laid end to end in d_gathered (each rt_tile_buffer_bytes long,
+ * rank order) into the row-major RGB8 frame d_rgb.  Runs on the context's device.
+ */
+int rt_untile_device(rt_ctx* ctx, int width, int height, int world, const void* d_gathered, void* d_rgb,
+                     void* hip_stream);
+
+/* Ray count of the current scene/state at this resolution, from the device's own counters (blocking). */
+int rt_count_rays(rt_ctx* ctx, int width, int height, rt_frame_stats* stats);
+
+/* Sizes of the flattened scene (blocking, host data only). */
+int rt_get_scene_info(rt_ctx* ctx, rt_scene_info* info);
+
+/* Message describing the last failure on this thread ("" if none). */
+const char* rt_last_error(void);
+
+/* ---- scene-ingest helpers (host only; no GPU needed) ---- */
+
+/*
+ * Camera basis from position, fov, yaw and pitch in degrees: Camera::Camera + Camera::updateDirection
+ * (Camera.cpp:5-20, 54-63).
+ */
+int rt_camera_look(const float position[3], float fov, float yaw, float pitch, rt_camera* out);
+
+/*
+ * Bakes loader output into a world-space model: the body of Model::Model (Model.cpp:62-126).  Inputs are per
+ * loaded vertex (LoadedVertices order): pos/nrm/ka/kd/ks 3 floats each, tex 2 floats; loaded_indices as
+ * produced by the OBJ loader.  Outputs: vertices[vert_count], indices[indices_count], bb[6] (whole-model box
+ * min then max), chunk_boxes[48] (eight boxes, min then max), chunk_indices[8 * *indices_per_box] where
+ * the caller provides room for 8 * 3 * ceil((indices_count / 3) / 8.0) ints.
+ */
+int rt_bake_model(const float* pos, const float* nrm, const float* tex, const float* ka, const float* kd,
+                  const float* ks, int vert_count, const uint32_t* loaded_indices, int indices_count,
+                  const float position[3], int size, rt_vertex* vertices, int32_t* indices, float* bb,
+                  float* chunk_boxes, int32_t* chunk_indices, int32_t* indices_per_box);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RT_API_H */
