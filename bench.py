@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mrays/s and ms/frame for the 1080p octree mesh scene (Crown + Vase + Crystal3, hard shadows,
+reflections with maxDepth 2, reflective floor) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A step is one frame: every rank renders the 64x64 tiles it owns (tile i -> rank i % N) of the same frame from its own
+resident copy of the scene, the tile buffers are gathered to rank 0 over RCCL, and rank 0 reassembles the frame.
+The scene, octree and output buffers are resident in HBM before the timed region.  Rank 0 prints one JSON line.
+"""
+import argparse
+import importlib.util
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
+FP32_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak
+
+
+def load_package():
+    name = "cuda_ray_tracer_amd"
+    if name in sys.modules:
+        return sys.modules[name]
+    pkg_dir = os.path.join(ROOT, "cuda-ray-tracer_amd")
+    spec = importlib.util.spec_from_file_location(name, os.path.join(pkg_dir, "__init__.py"), submodule_search_locations=[pkg_dir])
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def algorithmic_bytes_per_ray(st, pixels):
+    """32 B per child box slab-tested (24 B box + 8 B reference/meta), 36 B per triangle tested (three positions),
+    108 B per closest-hit attribute fetch (3 vertices x normal, Ka, Kd), 3 B of frame per pixel."""
+    rays = max(int(st.rays), 1)
+    return (32.0 * st.node_tests + 36.0 * st.tri_tests + 108.0 * st.attr_fetches + 3.0 * pixels) / rays
+
+
+def algorithmic_flops_per_ray(st, info, pixels):
+    """26 flop per child box, 51 per triangle test, 30/14/26 per sphere/plane/box test of the linear tables
+    (every ray visits every table entry once), ~120 per shaded hit (primary + reflection levels ~ rays/2)."""
+    rays = max(int(st.rays), 1)
+    linear = 30.0 * info.sphereCount + 14.0 * info.planeCount + 26.0 * info.AABBCount + 26.0 * info.modelCount
+    return (26.0 * st.node_tests + 51.0 * st.tri_tests) / rays + linear + 60.0
+
+
+def cpu_baseline(scenes, built, cfg, seconds_target=15.0):
+    """Times the CPU oracle (the reference's algorithm: box gate + every triangle) on a bounded sample: the same scene
+    and camera at a reduced resolution chosen so the run takes roughly `seconds_target` seconds."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import oracle_lib
+    O = oracle_lib.Oracle()
+    threads = min(16, os.cpu_count() or 1)
+    # probe at a tiny size to pick the sample size
+    t0 = time.perf_counter()
+    _, _, _, rays, _ = O.render(built.desc, built.camera, cfg, 48, 27, threads=threads, want_ids=False)
+    probe = max(time.perf_counter() - t0, 1e-3)
+    scale = max(1.0, min(40.0, (seconds_target / probe) ** 0.5))
+    w, h = int(48 * scale), int(27 * scale)
+    t0 = time.perf_counter()
+    _, _, _, rays, _ = O.render(built.desc, built.camera, cfg, w, h, threads=threads, want_ids=False)
+    dt = time.perf_counter() - t0
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": f"same scene and camera rendered at {w}x{h} ({rays} rays, {dt:.1f} s) by the CPU oracle, "
+                      f"box gate + brute-force triangle loop as the reference does, OpenMP over scanlines"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, help="benchmark configuration (3 = headline 1080p mesh scene)")
+    ap.add_argument("--detail", type=float, default=1.0)
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--out", type=str, default="", help="write the last frame as PNG (rank 0)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the render path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    load_package()
+    from cuda_ray_tracer_amd import binding, scenes
+
+    spec, cfg, w, h = scenes.config_scene(args.config, detail=args.detail)
+    if args.width and args.height:
+        w, h = args.width, args.height
+    built = scenes.build_scene(spec)
+    r = binding.Renderer(local_rank)
+    r.upload(built.desc)
+    r.set_state(built.camera, cfg)
+    info = r.scene_info()
+    pixels = w * h
+
+    # deterministic per-frame counters from the instrumented kernel (outside the timed region)
+    st = r.count_rays(w, h) if rank == 0 else None
+
+    stream = torch.cuda.current_stream().cuda_stream
+    frame = torch.empty(pixels * 3, dtype=torch.uint8, device=dev)
+    if world > 1:
+        tile_bytes = binding.tile_buffer_bytes(w, h, world)
+        tiles = torch.empty(tile_bytes, dtype=torch.uint8, device=dev)
+        gathered = torch.empty(tile_bytes * world, dtype=torch.uint8, device=dev) if rank == 0 else None
+        gather_list = list(gathered.chunk(world)) if rank == 0 else None
+
+    kernel_events = []
+
+    def step(record):
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        if world == 1:
+            r.render_device(w, h, frame.data_ptr(), stream)
+        else:
+            r.render_tiles_device(w, h, rank, world, tiles.data_ptr(), tile_bytes, stream)
+        if record:
+            e1.record()
+            kernel_events.append((e0, e1))
+        if world > 1:
+            dist.gather(tiles, gather_list, dst=0)
+            if rank == 0:
+                r.untile_device(w, h, world, gathered.data_ptr(), frame.data_ptr(), stream)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+
+    if rank == 0:
+        ms_per_step = elapsed * 1e3 / args.steps
+        rays = int(st.rays)
+        mrays = rays / (ms_per_step * 1e-3) / 1e6
+        b_ray = algorithmic_bytes_per_ray(st, pixels)
+        f_ray = algorithmic_flops_per_ray(st, info, pixels)
+        # the render kernel of this rank traces ~1/world of the frame's rays per launch
+        launch_rays = rays / world
+        achieved_gbs = b_ray * launch_rays / (kernel_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            try:
+                with open(tpath) as f:
+                    tj = json.load(f)
+                if tj.get("workload") == f"config{args.config}" and world == 1 and (w, h) == tuple(tj.get("size", ())):
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mrays/s + ms/frame, 1080p octree mesh scene, 1/2/4/8 MI355X",
+            "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"config{args.config}: Crown + Vase + Crystal3 procedural meshes, {w}x{h}, hard shadows, "
+                                   f"reflections maxDepth {cfg.maxDepth} with reflective floor, octree depth 8" if args.config == 3
+                       else f"config{args.config} at {w}x{h}",
+                       "triangles": int(info.triangleCount), "octree_nodes": int(info.nodeCount), "rays_per_frame": rays,
+                       "rays_per_pixel": rays / pixels, "tile": binding.RT_TILE,
+                       "parallelism": "1 GPU" if world == 1 else f"image tiles over {world} GPUs, scene replicated, RCCL gather to rank 0"},
+            "kernel_ms": kernel_ms,
+            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                         "bytes_per_ray": b_ray, "node_tests_per_ray": st.node_tests / rays, "tri_tests_per_ray": st.tri_tests / rays,
+                         "attr_fetches_per_ray": st.attr_fetches / rays,
+                         "fp32_valu_frac": f_ray * launch_rays / (kernel_ms * 1e-3) / (FP32_PEAK_TFLOPS * 1e12)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scenes, built, cfg)
+        if args.out:
+            from PIL import Image
+            Image.fromarray(frame.cpu().numpy().reshape(h, w, 3)).save(args.out)
+        print(json.dumps(out), flush=True)
+
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -99,3 +99,127 @@ def test_octree_shape_does_not_change_pixels(renderer, oracle, leaf, depth):
     rgb0, ids0, t0, st0 = renderer.render_ids(256, 144)
     assert np.array_equal(rgb, rgb0) and np.array_equal(ids, ids0) and np.array_equal(t.view(np.uint32), t0.view(np.uint32))
     assert st.rays == st0.rays
+
+
+def _render_tiles_emulated(renderer, w, h, world):
+    """One GPU plays every rank in turn: renders each rank's tiles into its slot of a gathered buffer, then untiles."""
+    import torch
+    from cuda_ray_tracer_amd import binding
+    per = binding.tile_buffer_bytes(w, h, world)
+    gathered = torch.zeros(per * world, dtype=torch.uint8, device="cuda:0")
+    frame = torch.zeros(w * h * 3, dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for rank in range(world):
+        renderer.render_tiles_device(w, h, rank, world, gathered.data_ptr() + rank * per, per, stream)
+    renderer.untile_device(w, h, world, gathered.data_ptr(), frame.data_ptr(), stream)
+    torch.cuda.synchronize()
+    return frame.cpu().numpy().reshape(h, w, 3)
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
+@pytest.mark.parametrize("size", [(640, 360), (333, 201)])
+def test_tile_sharded_frame_equals_single_gpu_frame(renderer, world, size):
+    """The multi-GPU invariant: tiles rendered per rank and reassembled == the one-launch frame, byte for byte."""
+    import torch  # noqa: F401  (first, so that the library shares torch's HIP runtime)
+    w, h = size
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.2)
+    built = scenes.build_scene(spec)
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    direct, _ = renderer.render(w, h)
+    tiled = _render_tiles_emulated(renderer, w, h, world)
+    assert np.array_equal(direct, tiled)
+
+
+def test_render_device_matches_host_entry_point(renderer):
+    import torch
+    spec, cfg, w, h = scenes.config_scene(1)
+    built = scenes.build_scene(spec)
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    host, _ = renderer.render(w, h)
+    frame = torch.zeros(w * h * 3, dtype=torch.uint8, device="cuda:0")
+    renderer.render_device(w, h, frame.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(host, frame.cpu().numpy().reshape(h, w, 3))
+
+
+def test_anti_aliasing_parity(renderer, oracle):
+    spec, cfg, w, h = scenes.config_scene(3, detail=0.15)
+    cfg.antiAliasing = 1
+    stats, st, o_rays = _run(renderer, oracle, spec, cfg, 192, 108)
+    print("AA", stats, st.rays)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0
+
+
+def test_soft_shadows_and_area_specular(renderer, oracle):
+    """Soft-shadow sample directions come from sinf/cosf/acosf, whose last bits differ between the host and device
+    math libraries, so a sample exactly on a shadow edge can flip: 1/softShadowNum of the colour on that pixel.
+    Tolerance: at most 0.5 % of pixels beyond 1 LSB; ids (primary rays) still identical."""
+    index, cfg = scenes.preset_config("C")
+    cfg.renderSoftShadows = 1; cfg.renderHardShadows = 0; cfg.areaLightSpecularEffect = 1
+    spec = scenes.reference_scene(index)
+    scenes.apply_frame_fixups(spec, cfg)
+    stats, st, o_rays = _run(renderer, oracle, spec, cfg, 320, 180)
+    print("soft", stats, st.rays)
+    assert_parity(stats, st.rays, o_rays, max_px_gt1_frac=0.005)
+    assert stats["id_mismatch"] == 0
+    spec, cfg, _, _ = scenes.config_scene(2, detail=0.3)
+    cfg.renderSoftShadows = 1; cfg.softShadowNum = 6
+    stats, st, o_rays = _run(renderer, oracle, spec, cfg, 192, 108)
+    print("soft mesh", stats, st.rays)
+    assert_parity(stats, st.rays, o_rays, max_px_gt1_frac=0.005)
+
+
+def test_lighting_toggles_and_cull_off(renderer, oracle):
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.15)
+    cfg.cullBackTriangles = 0; cfg.specularLighting = 0; cfg.renderAABBs = 0
+    stats, st, o_rays = _run(renderer, oracle, spec, cfg, 192, 108)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0
+    cfg.ambientLighting = 0; cfg.diffuseLighting = 0; cfg.specularLighting = 1; cfg.renderModels = 0
+    stats, st, o_rays = _run(renderer, oracle, spec, cfg, 192, 108)
+    assert_parity(stats, st.rays, o_rays)
+
+
+def test_dynamic_frame_state_moves_light_and_marker(renderer, oracle):
+    """rt_update_frame_state's dynamic block == re-uploading the scene with the moved light / marker / floor colour."""
+    from cuda_ray_tracer_amd import ctypes_types as T
+    index, cfg = scenes.preset_config("C")
+    spec = scenes.reference_scene(index)
+    scenes.apply_frame_fixups(spec, cfg)
+    built = scenes.build_scene(spec)
+    renderer.upload(built.desc)
+    dyn = T.Dynamic()
+    dyn.setLight = 1; dyn.lightPosition = T.Vec3(-20.0, -40.0, 5.0)
+    dyn.setSphere0 = 1; dyn.sphere0Position = T.Vec3(-20.0, -40.0, 5.0); dyn.sphere0Radius = 3.0
+    dyn.setPlane0 = 1; dyn.plane0AmbientColour = T.Vec3(0.5, 0.4, 0.3)
+    renderer.set_state(built.camera, cfg, dyn)
+    moved, _ = renderer.render(320, 180)
+    spec.light = (-20.0, -40.0, 5.0)
+    spec.spheres[0] = ((-20.0, -40.0, 5.0), 3.0) + tuple(spec.spheres[0][2:])
+    pos, n, mat, typ = spec.planes[0]
+    spec.planes[0] = (pos, n, ((0.5, 0.4, 0.3),) + tuple(mat[1:]), typ)
+    built2 = scenes.build_scene(spec)
+    o_rgb, _, _, _, _ = oracle.render(built2.desc, built2.camera, cfg, 320, 180)
+    stats = compare_frames(moved, None, None, o_rgb, None, None)
+    assert_parity(stats)
+
+
+def test_errors_are_reported_not_swallowed(pkg):
+    from cuda_ray_tracer_amd import binding
+    r = binding.Renderer(0)
+    try:
+        with pytest.raises(binding.RtError):
+            r.render(64, 64)                       # no scene yet
+        spec, cfg, _, _ = scenes.config_scene(1)
+        built = scenes.build_scene(spec)
+        r.upload(built.desc)
+        with pytest.raises(binding.RtError):
+            r.render(64, 64)                       # no frame state yet
+        cfg.boundingBox = 0
+        with pytest.raises(binding.RtError):
+            r.set_state(built.camera, cfg)         # unsupported mesh mode
+    finally:
+        r.close()
