@@ -46,6 +46,7 @@ def lib():
     L.rt_untile_device.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     L.rt_count_rays.argtypes = [vp, i32, i32, C.POINTER(T.FrameStats)]
     L.rt_get_scene_info.argtypes = [vp, C.POINTER(T.SceneInfo)]
+    L.rt_validate_scene_host.argtypes = [C.POINTER(T.SceneDesc), C.POINTER(T.SceneInfo)]
     L.rt_camera_look.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.POINTER(T.Camera)]
     L.rt_bake_model.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, C.POINTER(C.c_float), i32,
                                 vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
@@ -128,6 +129,13 @@ class Renderer:
         info = T.SceneInfo()
         _check(lib().rt_get_scene_info(self._ctx, C.byref(info)))
         return info
+
+
+def validate_scene_host(scene_desc):
+    """Flattens the scene on the host and checks the octree invariants; returns SceneInfo (raises on violation)."""
+    info = T.SceneInfo()
+    _check(lib().rt_validate_scene_host(C.byref(scene_desc), C.byref(info)))
+    return info
 
 
 def tile_buffer_bytes(width, height, world):

@@ -345,4 +345,23 @@ int rt_get_scene_info(rt_ctx* ctx, rt_scene_info* info) {
     return RT_OK;
 }
 
+int rt_validate_scene_host(const rt_scene_desc* scene, rt_scene_info* info) {
+    if (!scene) return fail(RT_ERR_INVALID, "null argument");
+    rt::FlatScene flat;
+    std::string err;
+    if (!rt::flattenScene(*scene, flat, err)) return fail(RT_ERR_INVALID, err);
+    if (!rt::validateFlatScene(*scene, flat, err)) return fail(RT_ERR_INVALID, err);
+    if (info) {
+        info->sphereCount = scene->sphereCount; info->planeCount = scene->planeCount; info->AABBCount = scene->AABBCount;
+        info->modelCount = scene->modelCount; info->triangleCount = flat.triangleCount; info->nodeCount = flat.nodeCount;
+        info->leafCount = flat.leafCount; info->maxDepth = flat.maxDepth;
+        info->deviceBytes = (int64_t)((flat.sphGeom.size() + flat.sphMat.size() + flat.plnP.size() + flat.plnN.size() + flat.plnMat.size() +
+                                       flat.boxMin.size() + flat.boxMax.size() + flat.boxMat.size() + flat.mdlGateMin.size() +
+                                       flat.mdlGateMax.size() + flat.mdlTightMin.size() + flat.mdlTightMax.size() + flat.mdlMat.size() +
+                                       flat.nodes.size() + flat.tris.size() + flat.attrs.size()) * sizeof(rt::F4) +
+                                      flat.mdlInfo.size() * sizeof(uint32_t));
+    }
+    return RT_OK;
+}
+
 }  // extern "C"

@@ -306,4 +306,94 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err) {
     return true;
 }
 
+namespace {
+
+struct Walker {
+    const rt_model& model;
+    const FlatScene& flat;
+    std::vector<uint8_t> seen;
+    std::string err;
+    int deepest = 0;
+
+    bool inside(const float lo[3], const float hi[3], const rt_vec3& p) const {
+        return p.x >= lo[0] && p.x <= hi[0] && p.y >= lo[1] && p.y <= hi[1] && p.z >= lo[2] && p.z <= hi[2];
+    }
+
+    bool leaf(uint32_t start, const float lo[3], const float hi[3]) {
+        for (uint32_t t = start;; t++) {
+            if ((size_t)t * 3 + 2 >= flat.tris.size()) { err = "leaf runs past the triangle array"; return false; }
+            uint32_t idw; std::memcpy(&idw, &flat.tris[(size_t)t * 3].w, 4);
+            uint32_t id = idw & ~kTriLast;
+            if (id >= seen.size()) { err = "triangle id out of range"; return false; }
+            if (seen[id]) { err = "triangle " + std::to_string(id) + " appears in two leaves"; return false; }
+            seen[id] = 1;
+            const int32_t* ix = model.indices + 3 * (int64_t)id;
+            const rt_vec3& p0 = model.vertices[ix[0]].position;
+            const F4& v0 = flat.tris[(size_t)t * 3];
+            if (v0.x != p0.x || v0.y != p0.y || v0.z != p0.z) { err = "triangle record does not match its vertex"; return false; }
+            for (int k = 0; k < 3; k++) {
+                if (!inside(lo, hi, model.vertices[ix[k]].position)) { err = "triangle " + std::to_string(id) + " pokes out of its leaf box"; return false; }
+            }
+            if (idw & kTriLast) return true;
+        }
+    }
+
+    bool node(uint32_t index, const float plo[3], const float phi[3], int depth) {
+        if (depth >= kMaxOctreeDepth) { err = "octree deeper than the traversal stack"; return false; }
+        deepest = std::max(deepest, depth + 1);
+        if ((size_t)(index + 1) * kNodeFloat4s > flat.nodes.size()) { err = "node index out of range"; return false; }
+        const F4* rec = &flat.nodes[(size_t)index * kNodeFloat4s];
+        uint32_t childBase, masks;
+        std::memcpy(&childBase, &rec[14].x, 4); std::memcpy(&masks, &rec[14].y, 4);
+        const uint32_t imask = masks & 0xffu, lmask = (masks >> 8) & 0xffu;
+        if (imask & lmask) { err = "slot marked both internal and leaf"; return false; }
+        uint32_t next = childBase;
+        for (int c = 0; c < 8; c++) {
+            float lo[3], hi[3];
+            for (int a = 0; a < 3; a++) {
+                const float* l = &rec[2 * a + c / 4].x; const float* h = &rec[6 + 2 * a + c / 4].x;
+                lo[a] = l[c % 4]; hi[a] = h[c % 4];
+            }
+            const bool used = ((imask | lmask) >> c) & 1u;
+            if (!used) {
+                if (!(lo[0] > hi[0])) { err = "empty slot without an inverted box"; return false; }
+                continue;
+            }
+            for (int a = 0; a < 3; a++) {
+                if (lo[a] < plo[a] - 2e-3f - 1e-5f * std::fabs(plo[a]) || hi[a] > phi[a] + 2e-3f + 1e-5f * std::fabs(phi[a])) { err = "child box outside its parent"; return false; }
+            }
+            if ((lmask >> c) & 1u) {
+                uint32_t ref; std::memcpy(&ref, &(&rec[12 + c / 4].x)[c % 4], 4);
+                if (!leaf(ref, lo, hi)) return false;
+            } else {
+                if (!node(next++, lo, hi, depth + 1)) return false;
+            }
+        }
+        return true;
+    }
+};
+
+}  // namespace
+
+bool validateFlatScene(const rt_scene_desc& scene, const FlatScene& flat, std::string& err) {
+    if ((int)flat.mdlInfo.size() != 4 * scene.modelCount) { err = "model table size mismatch"; return false; }
+    const float inf = std::numeric_limits<float>::infinity();
+    for (int m = 0; m < scene.modelCount; m++) {
+        const rt_model& model = scene.models[m];
+        const int64_t nTri = reachableTriangles(model.indicesCount);
+        Walker w{model, flat, std::vector<uint8_t>((size_t)nTri, 0), std::string(), 0};
+        const uint32_t rootRef = flat.mdlInfo[4 * m];
+        const float lo[3] = {-inf, -inf, -inf}, hi[3] = {inf, inf, inf};
+        bool ok = true;
+        if (rootRef == kNoRoot) ok = (nTri == 0);
+        else if (rootRef & kLeafFlag) ok = w.leaf(rootRef & ~kLeafFlag, lo, hi);
+        else ok = w.node(rootRef, lo, hi, 0);
+        if (!ok) { err = "model " + std::to_string(m) + ": " + (w.err.empty() ? "empty model has a root" : w.err); return false; }
+        for (int64_t t = 0; t < nTri; t++) {
+            if (!w.seen[(size_t)t]) { err = "model " + std::to_string(m) + ": triangle " + std::to_string(t) + " is in no leaf"; return false; }
+        }
+    }
+    return true;
+}
+
 }  // namespace rt

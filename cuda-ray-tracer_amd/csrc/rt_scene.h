@@ -32,6 +32,11 @@ int64_t reachableTriangles(int64_t indicesCount);
 // Fills `out` from `scene`.  Returns false and sets `err` if the scene fails validation.
 bool flattenScene(const rt_scene_desc& scene, FlatScene& out, std::string& err);
 
+// Walks the flattened octrees of `flat` (built from `scene`) and checks the invariants the traversal kernel relies on:
+// every reachable triangle of every model sits in exactly one leaf, inside the padded box of the slot that holds it;
+// child boxes nest; internal children are contiguous and in range; no path is deeper than the traversal stack.
+bool validateFlatScene(const rt_scene_desc& scene, const FlatScene& flat, std::string& err);
+
 // Packs one material into the three-float4 device form.
 void packMaterial(const rt_material& m, int objectType, uint32_t flags, F4 out[3]);
 

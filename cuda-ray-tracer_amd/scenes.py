@@ -277,6 +277,7 @@ def build_scene(spec, octree_max_depth=0, octree_leaf_triangles=0, meshes=None):
     d.lights = C.cast(light, C.POINTER(T.Light)); d.lightCount = 1
     d.octreeMaxDepth = octree_max_depth; d.octreeLeafTriangles = octree_leaf_triangles
     out.keep += [sph, pln, box, mdl, light]
+    d._keepalive = out.keep      # the descriptor alone keeps its arrays alive
     out.camera = binding.camera_look(spec.cam_pos, spec.fov, spec.cam_yaw, spec.cam_pitch)
     return out
 

@@ -118,6 +118,13 @@ int rt_count_rays(rt_ctx* ctx, int width, int height, rt_frame_stats* stats);
 /* Sizes of the flattened scene (blocking, host data only). */
 int rt_get_scene_info(rt_ctx* ctx, rt_scene_info* info);
 
+/*
+ * Host only (no GPU): flattens `scene` exactly as rt_upload_scene would and checks the octree invariants the
+ * traversal relies on (every reachable triangle in exactly one leaf and inside its padded box, nested child boxes,
+ * contiguous children, depth within the traversal stack).  Fills `info` (may be NULL).  No reference counterpart.
+ */
+int rt_validate_scene_host(const rt_scene_desc* scene, rt_scene_info* info);
+
 /* Message describing the last failure on this thread ("" if none). */
 const char* rt_last_error(void);
 

@@ -1,0 +1,78 @@
+"""Host-side scene flattening / octree construction, checked through rt_validate_scene_host (no GPU)."""
+import numpy as np
+import pytest
+
+from conftest import load_package
+from helpers import MATTE, mesh_from_triangles, simple_spec
+
+load_package()
+from cuda_ray_tracer_amd import binding, scenes  # noqa: E402
+
+
+@pytest.mark.parametrize("leaf,depth", [(1, 12), (2, 8), (4, 8), (8, 6), (64, 2), (1000000, 1)])
+def test_octree_invariants_hold_for_every_shape(leaf, depth):
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.3)
+    built = scenes.build_scene(spec, octree_max_depth=depth, octree_leaf_triangles=leaf)
+    info = binding.validate_scene_host(built.desc)
+    total = sum(m.triangle_count - 1 for m in built.model_meshes)      # the last triangle of each model is unreachable
+    assert info.triangleCount == total
+    assert info.maxDepth <= depth
+    assert info.leafCount >= 3
+
+
+def test_all_reference_and_benchmark_scenes_flatten():
+    for key in scenes.PRESETS:
+        index, cfg = scenes.preset_config(key)
+        built = scenes.build_scene(scenes.reference_scene(index, detail=0.4))
+        info = binding.validate_scene_host(built.desc)
+        assert info.modelCount == len(built.model_meshes)
+    for n in (1, 2, 3, 4):
+        spec, cfg, w, h = scenes.config_scene(n, detail=0.3)
+        binding.validate_scene_host(scenes.build_scene(spec).desc)
+
+
+def test_degenerate_inputs():
+    # empty model, one-triangle model (its only triangle is unreachable), coincident triangles (cannot be split)
+    tri = [[-1, -1, -5], [1, -1, -5], [0, 1, -5]]
+    for tris, reachable in (([tri], 0), ([tri, tri], 1), ([tri] * 40, 39)):
+        spec = simple_spec(models=[scenes.ModelSpec("test", (0, 0, 0), 1, MATTE)])
+        built = scenes.build_scene(spec, meshes={"test": mesh_from_triangles(tris)}, octree_leaf_triangles=2)
+        info = binding.validate_scene_host(built.desc)
+        assert info.triangleCount == reachable
+    # scene with no models at all
+    info = binding.validate_scene_host(scenes.build_scene(scenes.reference_scene(1)).desc)
+    assert info.triangleCount == 0 and info.nodeCount == 0
+
+
+def test_invalid_scenes_are_rejected():
+    spec, cfg, _, _ = scenes.config_scene(2, detail=0.2)
+    built = scenes.build_scene(spec)
+    built.desc.octreeMaxDepth = 13
+    with pytest.raises(binding.RtError, match="octreeMaxDepth"):
+        binding.validate_scene_host(built.desc)
+    built.desc.octreeMaxDepth = 0
+    built.desc.lightCount = 0
+    with pytest.raises(binding.RtError, match="light"):
+        binding.validate_scene_host(built.desc)
+    built.desc.lightCount = 1
+    built.keep[0]["indices"][0] = 10 ** 6
+    with pytest.raises(binding.RtError, match="index out of range"):
+        binding.validate_scene_host(built.desc)
+    built.keep[0]["indices"][0] = 0
+    built.keep[0]["vertices"][0].position.x = float("nan")
+    with pytest.raises(binding.RtError, match="non-finite"):
+        binding.validate_scene_host(built.desc)
+
+
+def test_meshgen_is_deterministic_and_outward_facing():
+    from cuda_ray_tracer_amd import meshgen
+    a, b = meshgen.generate("Crown", 0.3), meshgen.generate("Crown", 0.3)
+    assert np.array_equal(a.positions, b.positions) and np.array_equal(a.normals, b.normals)
+    for name in meshgen.GENERATORS:
+        m = meshgen.generate(name, 0.3)
+        P = m.positions.reshape(-1, 3, 3).astype(np.float64); N = m.normals.reshape(-1, 3, 3).astype(np.float64)
+        g = np.cross(P[:, 1] - P[:, 0], P[:, 2] - P[:, 0])
+        facing = np.einsum("ij,ij->i", g, N.sum(axis=1))
+        assert (facing >= -1e-9).all(), name                      # counter-clockwise around the normal
+        assert np.array_equal(m.indices, np.arange(len(m.indices)))
+        assert sum(c for _, _, c in m.groups) == m.triangle_count
