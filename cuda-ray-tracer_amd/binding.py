@@ -11,7 +11,7 @@ import numpy as np
 from . import ctypes_types as T
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "librt_amd.so")
+LIB_PATH = os.environ.get("RT_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "librt_amd.so")
 
 RT_TILE = 64
 _lib = None
@@ -46,6 +46,7 @@ def lib():
     L.rt_untile_device.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     L.rt_count_rays.argtypes = [vp, i32, i32, C.POINTER(T.FrameStats)]
     L.rt_get_scene_info.argtypes = [vp, C.POINTER(T.SceneInfo)]
+    L.rt_profile_waves.argtypes = [vp, i32, i32, vp, sz, C.POINTER(sz)]
     L.rt_validate_scene_host.argtypes = [C.POINTER(T.SceneDesc), C.POINTER(T.SceneInfo)]
     L.rt_camera_look.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.POINTER(T.Camera)]
     L.rt_bake_model.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, C.POINTER(C.c_float), i32,
@@ -124,6 +125,14 @@ class Renderer:
     def untile_device(self, width, height, world, d_gathered_ptr, d_rgb_ptr, stream=None):
         _check(lib().rt_untile_device(self._ctx, width, height, world, C.c_void_p(d_gathered_ptr), C.c_void_p(d_rgb_ptr),
                                       C.c_void_p(stream or 0)))
+
+    def profile_waves(self, width, height):
+        """Per-wave diagnostic records of one instrumented frame: uint64 array [waves, 10] (see rt_profile_waves)."""
+        cap = ((width + 63) // 64) * ((height + 63) // 64 + 1) * 16 * 4 + 8 * 64
+        buf = np.zeros((cap, 10), np.uint64)
+        n = C.c_size_t(0)
+        _check(lib().rt_profile_waves(self._ctx, width, height, buf.ctypes.data, cap, C.byref(n)))
+        return buf[:n.value]
 
     def scene_info(self):
         info = T.SceneInfo()

@@ -5,6 +5,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
@@ -63,6 +64,7 @@ struct rt_ctx {
     // host copies of the small tables that rt_update_frame_state may rewrite
     rt::F4 sphere0Geom{}; bool hasSphere0 = false;
     rt::F4 plane0Mat0{}; bool hasPlane0 = false;
+    int blockOrder = 2;
 };
 
 namespace {
@@ -96,6 +98,7 @@ rt::FrameParams frameFor(const rt_ctx* ctx, int width, int height, int rank, int
     p.tilesX = tilesAlong(width); p.tilesY = tilesAlong(height);
     p.ownedTiles = ownedTileCount(p.tilesX * p.tilesY, rank, world);
     p.compactOutput = compact ? 1 : 0;
+    p.blockOrder = ctx->blockOrder;
     return p;
 }
 
@@ -163,6 +166,7 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) return fail(RT_ERR_INVALID, "out of host memory");
     c->device = devices[0];
+    if (const char* e = std::getenv("RT_BLOCK_ORDER")) c->blockOrder = std::atoi(e);   // experiment switch
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, sizeof(unsigned long long) * rt::kCntCount);
     if (e != hipSuccess) { delete c; return failHip(e, "hipMalloc(counters)"); }
@@ -300,6 +304,26 @@ int rt_render_frame_ids(rt_ctx* ctx, int width, int height, uint8_t* rgb_out, in
 int rt_count_rays(rt_ctx* ctx, int width, int height, rt_frame_stats* stats) {
     if (!stats) return fail(RT_ERR_INVALID, "null stats");
     return renderToHost(ctx, width, height, nullptr, nullptr, nullptr, true, stats);
+}
+
+int rt_profile_waves(rt_ctx* ctx, int width, int height, uint64_t* clocks_out, size_t capacity_pairs, size_t* waves_out) {
+    int rc = checkFrameArgs(ctx, width, height);
+    if (rc) return rc;
+    if (!clocks_out || !waves_out) return fail(RT_ERR_INVALID, "null argument");
+    RT_HIP(hipSetDevice(ctx->device));
+    rt::FrameParams p = frameFor(ctx, width, height, 0, 1, false);
+    const size_t waves = (size_t)rt::launchGridBlocks(p) * 4;
+    *waves_out = waves;
+    if (capacity_pairs < waves) return fail(RT_ERR_CAPACITY, "clock buffer too small");
+    rc = ensureCapacity(&ctx->dFrame, &ctx->frameCap, (size_t)width * (size_t)height * 3);
+    if (rc) return rc;
+    void* d = nullptr;
+    RT_HIP(hipMalloc(&d, waves * 10 * sizeof(uint64_t)));
+    hipError_t e = rt::launchRender(ctx->scene, p, ctx->dFrame, nullptr, nullptr, nullptr, true, nullptr, static_cast<unsigned long long*>(d));
+    if (e == hipSuccess) e = hipMemcpy(clocks_out, d, waves * 10 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return failHip(e, "rt_profile_waves");
+    return RT_OK;
 }
 
 int rt_render_device(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_stream) {

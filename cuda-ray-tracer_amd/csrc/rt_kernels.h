@@ -12,7 +12,10 @@ namespace rt {
 // Renders the tiles FrameParams says this launch owns.  `out` is either the full row-major frame or the rank's
 // compact tile buffer (P.compactOutput).  ids / tbuf / counters may be null.  stats selects the instrumented kernel.
 hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
-                        unsigned long long* counters, bool stats, hipStream_t stream);
+                        unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks = nullptr);
+
+// Workgroups launchRender starts for these parameters (4 waves each).
+unsigned launchGridBlocks(const FrameParams& P);
 
 hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX,
                         size_t perRankBytes, hipStream_t stream);

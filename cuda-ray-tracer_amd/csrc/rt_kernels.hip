@@ -171,6 +171,22 @@ struct Counters { uint32_t rays, nodeTests, triTests, attrFetches, gateTests; };
 struct StackRef {
     uint32_t* base;   // &stackBase[0][tid]
     uint32_t* mask;
+    unsigned long long* prof;   // instrumented kernel only: 8 per-wave accumulators in LDS (see renderKernel)
+};
+
+// Wave-level section timer for the instrumented kernel: the first active lane adds the elapsed shader cycles and one
+// iteration to the wave's accumulators.
+template <bool STATS>
+struct SectionTimer {
+    unsigned long long t0;
+    RT_DEV SectionTimer() : t0(STATS ? __builtin_readcyclecounter() : 0ull) {}
+    RT_DEV void stop(const StackRef& stk, int slot) {
+        if (STATS) {
+            unsigned long long dt = __builtin_readcyclecounter() - t0;
+            unsigned long long active = __ballot(1);
+            if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)active) - 1)) { stk.prof[2 * slot] += dt; stk.prof[2 * slot + 1] += 1; }
+        }
+    }
 };
 
 // ---------------------------------------------------------------- octree traversal
@@ -183,41 +199,68 @@ RT_DEV uint32_t permuteOctants(uint32_t m, uint32_t oct) {
     return m;
 }
 
-RT_DEV float comp(f4_t a, f4_t b, int c) {
-    switch (c) {
-        case 0: return a.x; case 1: return a.y; case 2: return a.z; case 3: return a.w;
-        case 4: return b.x; case 5: return b.y; case 6: return b.z; default: return b.w;
-    }
+typedef float f2_t __attribute__((ext_vector_type(2)));
+
+// Per-ray constants of the approximate slab tests: rd = 1/d (v_rcp_f32, 1 ulp), ord = o * rd, and for each axis which
+// of a node's two float4 pairs holds the plane the ray enters through (lo if the direction is positive, hi otherwise).
+struct SlabRay {
+    V3 rd, ord;
+    uint32_t oct;            // bit a set: the ray travels towards -a (sign bit of d, so that -0 pairs with rd = -inf)
+    int nearX, nearY, nearZ; // float4 index of the entry planes inside a node record; the exit planes are 6 further / nearer
+};
+
+RT_DEV SlabRay makeSlabRay(V3 o, V3 d) {
+    SlabRay r;
+    r.rd = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
+    r.ord = mk(o.x * r.rd.x, o.y * r.rd.y, o.z * r.rd.z);
+    r.oct = (fbits(d.x) >> 31) | ((fbits(d.y) >> 31) << 1) | ((fbits(d.z) >> 31) << 2);
+    r.nearX = (r.oct & 1u) ? 6 : 0;
+    r.nearY = (r.oct & 2u) ? 8 : 2;
+    r.nearZ = (r.oct & 4u) ? 10 : 4;
+    return r;
 }
 
-// Conservative slab test of the eight child boxes of one node.  rd = 1/d (approximate), ord = o * rd.
-// Returns the bit mask of children whose padded box overlaps [0, tmax] along the ray.
-RT_DEV uint32_t testChildren(const F4* node, V3 rd, V3 ord, float tmax) {
-    f4_t lx0 = ld4(node + 0), lx1 = ld4(node + 1), ly0 = ld4(node + 2), ly1 = ld4(node + 3), lz0 = ld4(node + 4), lz1 = ld4(node + 5);
-    f4_t hx0 = ld4(node + 6), hx1 = ld4(node + 7), hy0 = ld4(node + 8), hy1 = ld4(node + 9), hz0 = ld4(node + 10), hz1 = ld4(node + 11);
+// Four children at once: entry/exit parameters along each axis, then interval overlap with [0, tmax].
+// fmaxf/fminf drop a NaN operand (inf - inf on an axis-parallel ray), which keeps the test conservative.
+RT_DEV uint32_t testFour(f4_t nx, f4_t ny, f4_t nz, f4_t fx, f4_t fy, f4_t fz, const SlabRay& r, float tmax) {
+    const f2_t rx = {r.rd.x, r.rd.x}, ry = {r.rd.y, r.rd.y}, rz = {r.rd.z, r.rd.z};
+    const f2_t ox = {-r.ord.x, -r.ord.x}, oy = {-r.ord.y, -r.ord.y}, oz = {-r.ord.z, -r.ord.z};
     uint32_t mask = 0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-        float ax = __builtin_fmaf(comp(lx0, lx1, c), rd.x, -ord.x), bx = __builtin_fmaf(comp(hx0, hx1, c), rd.x, -ord.x);
-        float ay = __builtin_fmaf(comp(ly0, ly1, c), rd.y, -ord.y), by = __builtin_fmaf(comp(hy0, hy1, c), rd.y, -ord.y);
-        float az = __builtin_fmaf(comp(lz0, lz1, c), rd.z, -ord.z), bz = __builtin_fmaf(comp(hz0, hz1, c), rd.z, -ord.z);
-        // fminf/fmaxf drop a NaN operand (0 * inf on an axis-parallel ray), which keeps the test conservative
-        float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
-        float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-        // widen by a few ulps of the larger magnitude: the fma form and the reciprocal are not exact
-        bool hit = tn <= tf + 4e-6f * fmaxf(fabsf(tn), fabsf(tf));
-        mask |= hit ? (1u << c) : 0u;
+    for (int h = 0; h < 2; h++) {
+        f2_t a = h ? f2_t{nx.z, nx.w} : f2_t{nx.x, nx.y}, b = h ? f2_t{ny.z, ny.w} : f2_t{ny.x, ny.y}, c = h ? f2_t{nz.z, nz.w} : f2_t{nz.x, nz.y};
+        f2_t e = h ? f2_t{fx.z, fx.w} : f2_t{fx.x, fx.y}, f = h ? f2_t{fy.z, fy.w} : f2_t{fy.x, fy.y}, g = h ? f2_t{fz.z, fz.w} : f2_t{fz.x, fz.y};
+        a = __builtin_elementwise_fma(a, rx, ox); b = __builtin_elementwise_fma(b, ry, oy); c = __builtin_elementwise_fma(c, rz, oz);
+        e = __builtin_elementwise_fma(e, rx, ox); f = __builtin_elementwise_fma(f, ry, oy); g = __builtin_elementwise_fma(g, rz, oz);
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            float tn = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], 0.0f));
+            float tf = fminf(fminf(e[k], f[k]), fminf(g[k], tmax));
+            mask |= (tn <= tf) ? (1u << (2 * h + k)) : 0u;
+        }
     }
     return mask;
 }
 
-RT_DEV bool tightBoxHit(V3 lo, V3 hi, V3 rd, V3 ord, float tmax) {
-    float ax = __builtin_fmaf(lo.x, rd.x, -ord.x), bx = __builtin_fmaf(hi.x, rd.x, -ord.x);
-    float ay = __builtin_fmaf(lo.y, rd.y, -ord.y), by = __builtin_fmaf(hi.y, rd.y, -ord.y);
-    float az = __builtin_fmaf(lo.z, rd.z, -ord.z), bz = __builtin_fmaf(hi.z, rd.z, -ord.z);
+// Conservative slab test of the eight child boxes of one node; returns the bit mask of children whose box overlaps
+// [0, tmax] along the ray.  Conservative because the host pads every child box by more than the worst-case error of
+// the fma / reciprocal form for coordinates and ray origins up to a few thousand units (rt_scene.cpp).
+RT_DEV uint32_t testChildren(const F4* node, const SlabRay& r, float tmax) {
+    const F4* nX = node + r.nearX; const F4* fX = node + (6 - r.nearX);
+    const F4* nY = node + r.nearY; const F4* fY = node + (10 - r.nearY);
+    const F4* nZ = node + r.nearZ; const F4* fZ = node + (14 - r.nearZ);
+    uint32_t lo4 = testFour(ld4(nX), ld4(nY), ld4(nZ), ld4(fX), ld4(fY), ld4(fZ), r, tmax);
+    uint32_t hi4 = testFour(ld4(nX + 1), ld4(nY + 1), ld4(nZ + 1), ld4(fX + 1), ld4(fY + 1), ld4(fZ + 1), r, tmax);
+    return lo4 | (hi4 << 4);
+}
+
+RT_DEV bool tightBoxHit(V3 lo, V3 hi, const SlabRay& r, float tmax) {
+    float ax = __builtin_fmaf(lo.x, r.rd.x, -r.ord.x), bx = __builtin_fmaf(hi.x, r.rd.x, -r.ord.x);
+    float ay = __builtin_fmaf(lo.y, r.rd.y, -r.ord.y), by = __builtin_fmaf(hi.y, r.rd.y, -r.ord.y);
+    float az = __builtin_fmaf(lo.z, r.rd.z, -r.ord.z), bz = __builtin_fmaf(hi.z, r.rd.z, -r.ord.z);
     float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
     float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-    return tn <= tf + 4e-6f * fmaxf(fabsf(tn), fabsf(tf));
+    return tn <= tf;
 }
 
 // Traces (o, d) against every eligible model.
@@ -230,12 +273,12 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
     const int nMdl = S.nMdl;
     if (nMdl == 0) return false;
 
-    // approximate reciprocal direction for the child-box tests only
-    V3 rd = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    V3 ord = mk(o.x * rd.x, o.y * rd.y, o.z * rd.z);
-    const uint32_t oct = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    const SlabRay sr = makeSlabRay(o, d);   // approximate arithmetic, used for the child-box tests only
+    const uint32_t oct = sr.oct;
 
     int m = -1;                 // current model
+    int chunk = -64;            // first model of the 64-model chunk whose gate bits are in gateBits
+    unsigned long long gateBits = 0;
     int bestTriInModel = 0x7fffffff;   // id of the current best hit if it lies in model m, else "none"
     uint32_t base = 0, imask = 0, hits = 0;   // children still to visit below the current node
     int sp = 0;
@@ -246,46 +289,62 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
     for (;;) {
         // ---- descend until this lane has triangles to test or has run out of models
         while (!done && pend == 0) {
+            SectionTimer<STATS> timerA;
+            if (hits == 0 && sp > 0) {      // siblings left on an upper level
+                sp--;
+                base = stk.base[sp * 256];
+                uint32_t packed = stk.mask[sp * 256];
+                imask = packed & 0xffu;
+                hits = packed >> 8;
+            }
             uint32_t node;
             if (hits != 0) {
                 uint32_t k = __builtin_ctz(hits);
                 hits &= hits - 1;
                 uint32_t c = k ^ oct;
                 node = base + __builtin_popcount(imask & ((1u << c) - 1u));
-            } else if (sp > 0) {
-                sp--;
-                base = stk.base[sp * 256];
-                uint32_t packed = stk.mask[sp * 256];
-                imask = packed & 0xffu;
-                hits = packed >> 8;
-                continue;
             } else {
-                // next model whose gate the ray passes
+                // next model the ray can reach: bit set in gateBits, tight box still within range
                 uint32_t rootRef = kNoRoot;
                 for (;;) {
-                    m++;
-                    if (m >= nMdl) break;
-                    if (skipDebug || ANYHIT) {
-                        uint32_t flags = fbits(S.mdlMat[3 * m + 2].w);
-                        if (flags & 1u) continue;
+                    if (gateBits == 0) {
+                        // Evaluate a whole chunk of models at once: every lane that gets here runs the same trip count, so
+                        // the expensive exact gate (six divisions per model) is not serialised across lanes.
+                        chunk += 64;
+                        if (chunk >= nMdl) break;
+                        const int end = (nMdl - chunk) < 64 ? (nMdl - chunk) : 64;
+                        for (int j = 0; j < end; j++) {
+                            const int mm = chunk + j;
+                            if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) continue;
+                            // cheap conservative test of the triangles' own box first; the reference's gate only for
+                            // rays that could reach a triangle at all - the order does not change the result
+                            if (!tightBoxHit(xyz(ld4(S.mdlTightMin + mm)), xyz(ld4(S.mdlTightMax + mm)), sr, ANYHIT ? FAR_T : best.t)) continue;
+                            if (STATS) cnt.gateTests++;
+                            float tGate;
+                            if (!boxHit(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, tGate)) continue;
+                            gateBits |= 1ull << j;
+                        }
+                        if (gateBits == 0) continue;
                     }
-                    if (STATS) cnt.gateTests++;
-                    float tGate;
-                    if (!boxHit(xyz(ld4(S.mdlGateMin + m)), xyz(ld4(S.mdlGateMax + m)), o, d, tGate)) continue;
-                    float tmax = ANYHIT ? FAR_T : best.t;
-                    if (!tightBoxHit(xyz(ld4(S.mdlTightMin + m)), xyz(ld4(S.mdlTightMax + m)), rd, ord, tmax)) continue;
+                    const int j = __builtin_ctzll(gateBits);
+                    gateBits &= gateBits - 1;
+                    m = chunk + j;
+                    // the closest hit may have moved in since the chunk was evaluated
+                    if (!ANYHIT && !tightBoxHit(xyz(ld4(S.mdlTightMin + m)), xyz(ld4(S.mdlTightMax + m)), sr, best.t)) continue;
                     rootRef = S.mdlInfo[4 * m];
                     if (rootRef == kNoRoot) continue;
                     break;
                 }
-                if (m >= nMdl) { done = true; break; }
+                timerA.stop(stk, 2);
+                if (rootRef == kNoRoot) { done = true; break; }
+                timerA = SectionTimer<STATS>();
                 bestTriInModel = 0x7fffffff;
                 if (rootRef & kLeafFlag) { pend = 1u; lr0 = rootRef & ~kLeafFlag; lr1 = lr0; lr2 = lr0; lr3 = lr0; lr4 = lr0; lr5 = lr0; lr6 = lr0; lr7 = lr0; break; }
                 node = rootRef;
             }
 
             const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
-            uint32_t hmask = testChildren(np, rd, ord, ANYHIT ? FAR_T : best.t);
+            uint32_t hmask = testChildren(np, sr, ANYHIT ? FAR_T : best.t);
             u4_t meta = *reinterpret_cast<const u4_t*>(np + 14);
             uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
             if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
@@ -303,6 +362,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                 lr0 = ra.x; lr1 = ra.y; lr2 = ra.z; lr3 = ra.w; lr4 = rb.x; lr5 = rb.y; lr6 = rb.z; lr7 = rb.w;
                 pend = permuteOctants(lhit, oct);
             }
+            timerA.stop(stk, 0);
         }
         if (pend == 0) break;   // done
 
@@ -314,6 +374,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
             uint32_t start = c == 0 ? lr0 : c == 1 ? lr1 : c == 2 ? lr2 : c == 3 ? lr3 : c == 4 ? lr4 : c == 5 ? lr5 : c == 6 ? lr6 : lr7;
             const F4* tp = S.tris + (size_t)start * 3;
             for (;;) {
+                SectionTimer<STATS> timerB;
                 f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
                 tp += 3;
                 uint32_t idw = fbits(A.w);
@@ -345,6 +406,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                         }
                     }
                 }
+                timerB.stop(stk, 1);
                 if ((idw & kTriLast) || (ANYHIT && found)) break;
             }
             if (ANYHIT && found) { pend = 0; done = true; hits = 0; sp = 0; }
@@ -628,16 +690,35 @@ RT_DEV uint32_t xcdRemap(uint32_t b, uint32_t n) {
 
 template <bool STATS>
 __global__ __launch_bounds__(256) void renderKernel(DevScene S, FrameParams P, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
-                                                    float* __restrict__ tbuf, unsigned long long* __restrict__ counters) {
+                                                    float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
+                                                    unsigned long long* __restrict__ waveClocks) {
+    const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
     __shared__ uint32_t stackBase[kMaxOctreeDepth * 256];
     __shared__ uint32_t stackMask[kMaxOctreeDepth * 256];
+    __shared__ unsigned long long profile[STATS ? 32 : 1];   // 8 accumulators per wave (instrumented kernel only)
     const uint32_t tid = threadIdx.x;
-    StackRef stk; stk.base = stackBase + tid; stk.mask = stackMask + tid;
+    StackRef stk; stk.base = stackBase + tid; stk.mask = stackMask + tid; stk.prof = profile + (STATS ? 8 * (tid >> 6) : 0);
+    if (STATS) { if (tid < 32) profile[tid] = 0; __syncthreads(); }
 
     constexpr int kBlocksPerTileSide = RT_TILE_PX / 16;                     // 16x16 pixel blocks along a tile edge
     constexpr int kBlocksPerTile = kBlocksPerTileSide * kBlocksPerTileSide;
-    const uint32_t b = xcdRemap(blockIdx.x, gridDim.x);
-    const uint32_t localTile = b / kBlocksPerTile, inTile = b % kBlocksPerTile;
+    uint32_t localTile, inTile;
+    if (P.blockOrder == 2) {
+        // Workgroup B runs on XCD B % 8.  XCD x takes the owned tiles x, x + 8, x + 16, ...: the 16 blocks of a tile share
+        // one L2, and every XCD gets the same mix of cheap and expensive screen regions.
+        const uint32_t xcd = blockIdx.x % 8u, i = blockIdx.x / 8u;
+        localTile = (i / kBlocksPerTile) * 8u + xcd;
+        inTile = i % kBlocksPerTile;
+        if (localTile >= (uint32_t)P.ownedTiles) {
+            if (STATS && waveClocks && (threadIdx.x & 63u) == 0) {
+                for (int k = 0; k < 10; k++) waveClocks[10 * (blockIdx.x * 4u + (threadIdx.x >> 6)) + k] = 0;
+            }
+            return;
+        }
+    } else {
+        const uint32_t b = P.blockOrder == 1 ? xcdRemap(blockIdx.x, gridDim.x) : blockIdx.x;
+        localTile = b / kBlocksPerTile; inTile = b % kBlocksPerTile;
+    }
     const uint32_t tile = localTile * (uint32_t)P.world + (uint32_t)P.rank;
     const uint32_t tileX = tile % (uint32_t)P.tilesX, tileY = tile / (uint32_t)P.tilesX;
     // wave w of the block owns the 8x8 quadrant (w & 1, w >> 1); lane l is pixel (l & 7, l >> 3) of it
@@ -684,6 +765,12 @@ __global__ __launch_bounds__(256) void renderKernel(DevScene S, FrameParams P, u
         }
     }
 
+    if (STATS && waveClocks && lane == 0) {      // diagnostic: when this wave started and finished, and its section sums
+        unsigned long long* rec = waveClocks + 10 * (blockIdx.x * 4u + wave);
+        rec[0] = clockStart;
+        rec[1] = __builtin_amdgcn_s_memrealtime();
+        for (int k = 0; k < 8; k++) rec[2 + k] = stk.prof[k];
+    }
     // one atomic per wave and counter
     if (counters) {
         uint32_t vals[kCntCount] = {cnt.rays, cnt.nodeTests, cnt.triTests, cnt.attrFetches, cnt.gateTests};
@@ -723,13 +810,18 @@ __global__ __launch_bounds__(256) void untileKernel(const uint8_t* __restrict__ 
 
 // ---------------------------------------------------------------- launch wrappers (host)
 
-hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
-                        unsigned long long* counters, bool stats, hipStream_t stream) {
-    if (P.ownedTiles <= 0) return hipSuccess;
+unsigned launchGridBlocks(const FrameParams& P) {
     constexpr int kBlocksPerTile = (RT_TILE_PX / 16) * (RT_TILE_PX / 16);
-    dim3 grid((unsigned)(P.ownedTiles * kBlocksPerTile)), block(256);
-    if (stats) hipLaunchKernelGGL(renderKernel<true>, grid, block, 0, stream, S, P, out, ids, tbuf, counters);
-    else hipLaunchKernelGGL(renderKernel<false>, grid, block, 0, stream, S, P, out, ids, tbuf, counters);
+    const int tilesLaunched = P.blockOrder == 2 ? ((P.ownedTiles + 7) / 8) * 8 : P.ownedTiles;
+    return (unsigned)(tilesLaunched * kBlocksPerTile);
+}
+
+hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
+                        unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks) {
+    if (P.ownedTiles <= 0) return hipSuccess;
+    dim3 grid(launchGridBlocks(P)), block(256);
+    if (stats) hipLaunchKernelGGL(renderKernel<true>, grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks);
+    else hipLaunchKernelGGL(renderKernel<false>, grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks);
     return hipGetLastError();
 }
 

@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""Prints the distribution of per-wave run times and the occupancy timeline of one frame (diagnostic)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import load_package  # noqa: E402
+
+load_package()
+from cuda_ray_tracer_amd import binding, scenes  # noqa: E402
+
+cfg_no = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+spec, cfg, w, h = scenes.config_scene(cfg_no)
+built = scenes.build_scene(spec)
+r = binding.Renderer(0)
+r.upload(built.desc); r.set_state(built.camera, cfg)
+r.render(w, h)
+clk = r.profile_waves(w, h)
+clk = r.profile_waves(w, h)
+valid = clk[:, 1] > 0
+s, e = clk[valid, 0].astype(np.int64), clk[valid, 1].astype(np.int64)
+t0 = s.min()
+dur = (e - s) / 100.0          # microseconds
+print(f"waves {valid.sum()}  frame span {(e.max() - t0) / 100.0:.1f} us  sum of wave time {dur.sum() / 1e3:.1f} ms  mean {dur.mean():.1f} us")
+print("duration percentiles (us):", {p: round(float(np.percentile(dur, p)), 1) for p in (50, 90, 99, 99.9, 100)})
+span = (e.max() - t0)
+bins = 20
+edges = np.linspace(0, span, bins + 1)
+for i in range(bins):
+    a, b = edges[i], edges[i + 1]
+    active = (np.minimum(e - t0, b) - np.maximum(s - t0, a)).clip(min=0).sum() / (b - a)
+    print(f"  {a / 100:8.1f}-{b / 100:8.1f} us: {active:7.1f} waves resident on average")
+sec = clk[valid, 2:].astype(np.float64)
+tot_cycles = dur * 2400.0   # rough: 2.4 GHz
+print("share of wave time (all waves): node visits %.1f%%, triangle tests %.1f%%, model gates %.1f%%, pops %.1f%%" % tuple(100 * sec[:, k].sum() / tot_cycles.sum() for k in (0, 2, 4, 6)))
+heavy = dur > np.percentile(dur, 99)
+print("heavy 1%% waves: node visits %.1f%% (%.0f iters/wave, %.0f cyc/iter), triangle tests %.1f%% (%.0f iters, %.0f cyc/iter), gates %.1f%% (%.0f iters, %.0f cyc/iter)" % (
+    100 * sec[heavy, 0].sum() / tot_cycles[heavy].sum(), sec[heavy, 1].mean(), sec[heavy, 0].sum() / max(sec[heavy, 1].sum(), 1),
+    100 * sec[heavy, 2].sum() / tot_cycles[heavy].sum(), sec[heavy, 3].mean(), sec[heavy, 2].sum() / max(sec[heavy, 3].sum(), 1),
+    100 * sec[heavy, 4].sum() / tot_cycles[heavy].sum(), sec[heavy, 5].mean(), sec[heavy, 4].sum() / max(sec[heavy, 5].sum(), 1)))
+order = np.argsort(-dur)[:10]
+idx = np.nonzero(valid)[0][order]
+print("slowest waves (wave index, start us, dur us):", [(int(i), round(float((clk[i, 0] - t0) / 100.0), 1), round(float((clk[i, 1] - clk[i, 0]) / 100.0), 1)) for i in idx])
