@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--detail", type=float, default=1.0)
     ap.add_argument("--width", type=int, default=0)
     ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--leaf", type=int, default=0, help="octree leaf size override (0 = library default)")
+    ap.add_argument("--depth", type=int, default=0, help="octree depth cap override (0 = library default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out", type=str, default="", help="write the last frame as PNG (rank 0)")
     args = ap.parse_args()
@@ -104,7 +106,7 @@ def main():
     spec, cfg, w, h = scenes.config_scene(args.config, detail=args.detail)
     if args.width and args.height:
         w, h = args.width, args.height
-    built = scenes.build_scene(spec)
+    built = scenes.build_scene(spec, octree_max_depth=args.depth, octree_leaf_triangles=args.leaf)
     r = binding.Renderer(local_rank)
     r.upload(built.desc)
     r.set_state(built.camera, cfg)

@@ -65,6 +65,11 @@ struct rt_ctx {
     rt::F4 sphere0Geom{}; bool hasSphere0 = false;
     rt::F4 plane0Mat0{}; bool hasPlane0 = false;
     int blockOrder = 2;
+    // Cost-ordered dispatch: per-tile cost of the previous frame and the order derived from it (device, fixed capacity
+    // so that the stream entry points never allocate).  orderKey identifies the frame geometry the order belongs to.
+    uint32_t* dTileCost = nullptr; uint32_t* dTileOrder = nullptr;
+    long long orderKey = -1;
+    bool costOrdering = true;
 };
 
 namespace {
@@ -75,6 +80,8 @@ void freeScene(rt_ctx* c) {
     c->scene = rt::DevScene{};
     c->haveScene = false;
 }
+
+constexpr int kMaxOrderedTiles = 1 << 16;   // frames with more tiles per rank are rendered in plain tile order
 
 int tilesAlong(int pixels) { return (pixels + RT_TILE - 1) / RT_TILE; }
 
@@ -102,6 +109,26 @@ rt::FrameParams frameFor(const rt_ctx* ctx, int width, int height, int rank, int
     return p;
 }
 
+// Launches the render kernel for `p` with cost-ordered dispatch: tiles are started in the order of their measured cost
+// on the previous frame of the same geometry, and this frame's costs are ranked afterwards for the next one.
+int launchOrdered(rt_ctx* ctx, const rt::FrameParams& p, uint8_t* out, int32_t* ids, float* tbuf, unsigned long long* counters,
+                  bool instrumented, hipStream_t stream, unsigned long long* waveClocks = nullptr) {
+    const bool use = ctx->costOrdering && p.blockOrder == 2 && p.ownedTiles > 0 && p.ownedTiles <= kMaxOrderedTiles;
+    if (!use) {
+        RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks));
+        return RT_OK;
+    }
+    const long long key = ((long long)p.width << 40) ^ ((long long)p.height << 20) ^ ((long long)p.world << 8) ^ (long long)p.rank;
+    const bool haveOrder = ctx->orderKey == key;
+    if (!haveOrder) RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * (size_t)p.ownedTiles, stream));
+    RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks,
+                            haveOrder ? ctx->dTileOrder : nullptr, ctx->dTileCost));
+    RT_HIP(rt::launchRankTiles(ctx->dTileCost, ctx->dTileOrder, p.ownedTiles, stream));
+    RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * (size_t)p.ownedTiles, stream));
+    ctx->orderKey = key;
+    return RT_OK;
+}
+
 template <typename T>
 int ensureCapacity(T** buf, size_t* cap, size_t need) {
     if (*cap >= need) return RT_OK;
@@ -127,8 +154,8 @@ int renderToHost(rt_ctx* ctx, int width, int height, uint8_t* rgbOut, int32_t* i
     rt::FrameParams p = frameFor(ctx, width, height, 0, 1, false);
     RT_HIP(hipMemsetAsync(ctx->dCounters, 0, sizeof(unsigned long long) * rt::kCntCount, nullptr));
     RT_HIP(hipEventRecord(ctx->evStart, nullptr));
-    RT_HIP(rt::launchRender(ctx->scene, p, ctx->dFrame, idsOut ? ctx->dIds : nullptr, tOut ? ctx->dT : nullptr, ctx->dCounters,
-                            instrumented, nullptr));
+    rc = launchOrdered(ctx, p, ctx->dFrame, idsOut ? ctx->dIds : nullptr, tOut ? ctx->dT : nullptr, ctx->dCounters, instrumented, nullptr);
+    if (rc) return rc;
     RT_HIP(hipEventRecord(ctx->evStop, nullptr));
     if (rgbOut) RT_HIP(hipMemcpyAsync(rgbOut, ctx->dFrame, pixels * 3, hipMemcpyDeviceToHost, nullptr));
     if (idsOut) RT_HIP(hipMemcpyAsync(idsOut, ctx->dIds, pixels * 2 * sizeof(int32_t), hipMemcpyDeviceToHost, nullptr));
@@ -166,11 +193,17 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     rt_ctx* c = new (std::nothrow) rt_ctx();
     if (!c) return fail(RT_ERR_INVALID, "out of host memory");
     c->device = devices[0];
-    if (const char* e = std::getenv("RT_BLOCK_ORDER")) c->blockOrder = std::atoi(e);   // experiment switch
+    if (const char* e = std::getenv("RT_BLOCK_ORDER")) c->blockOrder = std::atoi(e);   // experiment switches
+    if (const char* e = std::getenv("RT_COST_ORDER")) c->costOrdering = std::atoi(e) != 0;
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, sizeof(unsigned long long) * rt::kCntCount);
     if (e != hipSuccess) { delete c; return failHip(e, "hipMalloc(counters)"); }
     c->dCounters = static_cast<unsigned long long*>(p);
+    void* q = nullptr;
+    e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles);
+    if (e == hipSuccess) { c->dTileCost = static_cast<uint32_t*>(q); e = hipMemset(q, 0, sizeof(uint32_t) * kMaxOrderedTiles); }
+    if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles); if (e == hipSuccess) c->dTileOrder = static_cast<uint32_t*>(q); }
+    if (e != hipSuccess) { rt_destroy(c); return failHip(e, "hipMalloc(tile order)"); }
     e = hipEventCreate(&c->evStart);
     if (e == hipSuccess) e = hipEventCreate(&c->evStop);
     if (e != hipSuccess) { rt_destroy(c); return failHip(e, "hipEventCreate"); }
@@ -187,6 +220,8 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->dIds) (void)hipFree(ctx->dIds);
     if (ctx->dT) (void)hipFree(ctx->dT);
     if (ctx->dCounters) (void)hipFree(ctx->dCounters);
+    if (ctx->dTileCost) (void)hipFree(ctx->dTileCost);
+    if (ctx->dTileOrder) (void)hipFree(ctx->dTileOrder);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     delete ctx;
@@ -312,14 +347,16 @@ int rt_profile_waves(rt_ctx* ctx, int width, int height, uint64_t* clocks_out, s
     if (!clocks_out || !waves_out) return fail(RT_ERR_INVALID, "null argument");
     RT_HIP(hipSetDevice(ctx->device));
     rt::FrameParams p = frameFor(ctx, width, height, 0, 1, false);
-    const size_t waves = (size_t)rt::launchGridBlocks(p) * 4;
+    const size_t waves = (size_t)rt::launchGridBlocks(p);
     *waves_out = waves;
     if (capacity_pairs < waves) return fail(RT_ERR_CAPACITY, "clock buffer too small");
     rc = ensureCapacity(&ctx->dFrame, &ctx->frameCap, (size_t)width * (size_t)height * 3);
     if (rc) return rc;
     void* d = nullptr;
     RT_HIP(hipMalloc(&d, waves * 10 * sizeof(uint64_t)));
-    hipError_t e = rt::launchRender(ctx->scene, p, ctx->dFrame, nullptr, nullptr, nullptr, true, nullptr, static_cast<unsigned long long*>(d));
+    hipError_t e = hipSuccess;
+    rc = launchOrdered(ctx, p, ctx->dFrame, nullptr, nullptr, nullptr, true, nullptr, static_cast<unsigned long long*>(d));
+    if (rc) { (void)hipFree(d); return rc; }
     if (e == hipSuccess) e = hipMemcpy(clocks_out, d, waves * 10 * sizeof(uint64_t), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return failHip(e, "rt_profile_waves");
@@ -331,8 +368,7 @@ int rt_render_device(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_
     if (rc) return rc;
     if (!d_rgb) return fail(RT_ERR_INVALID, "null device buffer");
     rt::FrameParams p = frameFor(ctx, width, height, 0, 1, false);
-    RT_HIP(rt::launchRender(ctx->scene, p, static_cast<uint8_t*>(d_rgb), nullptr, nullptr, nullptr, false, static_cast<hipStream_t>(hip_stream)));
-    return RT_OK;
+    return launchOrdered(ctx, p, static_cast<uint8_t*>(d_rgb), nullptr, nullptr, nullptr, false, static_cast<hipStream_t>(hip_stream));
 }
 
 size_t rt_tile_buffer_bytes(int width, int height, int world) {
@@ -349,8 +385,7 @@ int rt_render_tiles_device(rt_ctx* ctx, int width, int height, int rank, int wor
     if (!d_tiles) return fail(RT_ERR_INVALID, "null device buffer");
     if (capacity_bytes < rt_tile_buffer_bytes(width, height, world)) return fail(RT_ERR_CAPACITY, "tile buffer too small");
     rt::FrameParams p = frameFor(ctx, width, height, rank, world, true);
-    RT_HIP(rt::launchRender(ctx->scene, p, static_cast<uint8_t*>(d_tiles), nullptr, nullptr, nullptr, false, static_cast<hipStream_t>(hip_stream)));
-    return RT_OK;
+    return launchOrdered(ctx, p, static_cast<uint8_t*>(d_tiles), nullptr, nullptr, nullptr, false, static_cast<hipStream_t>(hip_stream));
 }
 
 int rt_untile_device(rt_ctx* ctx, int width, int height, int world, const void* d_gathered, void* d_rgb, void* hip_stream) {

@@ -72,7 +72,7 @@ struct FrameParams {
     // tile sharding: this launch renders tiles rank, rank + world, ... ; tilesX/tilesY = tile grid
     int32_t rank, world, tilesX, tilesY, ownedTiles;
     int32_t compactOutput;     // 1: write tile-major into the rank's compact buffer, 0: row-major full frame
-    int32_t blockOrder;        // workgroup -> screen block mapping: 0 identity, 1 XCD-contiguous runs, 2 tiles interleaved over XCDs
+    int32_t blockOrder;        // workgroup -> tile mapping: 0 tile by tile, 2 tiles interleaved over the XCDs
     float camPos[3], camUp[3], camRight[3], camDir[3], fovFactor;
     // SceneConfig
     float shadowBias, shadowIntensity;

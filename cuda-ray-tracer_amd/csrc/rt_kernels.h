@@ -12,9 +12,13 @@ namespace rt {
 // Renders the tiles FrameParams says this launch owns.  `out` is either the full row-major frame or the rank's
 // compact tile buffer (P.compactOutput).  ids / tbuf / counters may be null.  stats selects the instrumented kernel.
 hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
-                        unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks = nullptr);
+                        unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks = nullptr,
+                        const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr);
 
-// Workgroups launchRender starts for these parameters (4 waves each).
+// order = this rank's tiles sorted by descending cost (ties by index).
+hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, int n, hipStream_t stream);
+
+// Workgroups (= waves) launchRender starts for these parameters.
 unsigned launchGridBlocks(const FrameParams& P);
 
 hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX,

@@ -26,6 +26,7 @@ typedef float f4_t __attribute__((ext_vector_type(4)));
 typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 
 #define RT_DEV __device__ __forceinline__
+constexpr int kBlockThreads = 64;   // render workgroups are single waves
 #define FAR_T 999.0f
 
 struct V3 { float x, y, z; };
@@ -292,8 +293,8 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
             SectionTimer<STATS> timerA;
             if (hits == 0 && sp > 0) {      // siblings left on an upper level
                 sp--;
-                base = stk.base[sp * 256];
-                uint32_t packed = stk.mask[sp * 256];
+                base = stk.base[sp * kBlockThreads];
+                uint32_t packed = stk.mask[sp * kBlockThreads];
                 imask = packed & 0xffu;
                 hits = packed >> 8;
             }
@@ -349,8 +350,8 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
             uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
             if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
             if (hits != 0) {   // keep the siblings that are still waiting
-                stk.base[sp * 256] = base;
-                stk.mask[sp * 256] = imask | (hits << 8);
+                stk.base[sp * kBlockThreads] = base;
+                stk.mask[sp * kBlockThreads] = imask | (hits << 8);
                 sp++;
             }
             base = meta.x;
@@ -681,50 +682,51 @@ RT_DEV uint8_t packChannel(float c) {
     return (uint8_t)f2iRz(v);
 }
 
-// Block b of the launch -> which 16x16 pixel block of which owned tile.  Consecutive workgroups go to different
-// XCDs, so the id is remapped to give each XCD (own L2) a contiguous run of screen blocks.
-RT_DEV uint32_t xcdRemap(uint32_t b, uint32_t n) {
-    const uint32_t q = n / 8u, r = n % 8u, xcd = b % 8u, i = b / 8u;
-    return (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + i;
-}
+// One wave per workgroup: a workgroup whose four waves finish at very different times would hold its slots until
+// the slowest is done, and wave run times inside one 16x16 block differ by more than 10x at object silhouettes.
+constexpr int kWavesPerTileSide = RT_TILE_PX / 8;
+constexpr int kWavesPerTile = kWavesPerTileSide * kWavesPerTileSide;
+
+// Bits 0,2,4 of v -> bits 0,1,2 (one coordinate of a Z-order index).
+RT_DEV uint32_t evenBits3(uint32_t v) { return (v & 1u) | ((v >> 1) & 2u) | ((v >> 2) & 4u); }
 
 template <bool STATS>
-__global__ __launch_bounds__(256) void renderKernel(DevScene S, FrameParams P, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
+__global__ __launch_bounds__(kBlockThreads) void renderKernel(DevScene S, FrameParams P, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
                                                     float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
-                                                    unsigned long long* __restrict__ waveClocks) {
+                                                    unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
+                                                    uint32_t* __restrict__ tileCost) {
     const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
-    __shared__ uint32_t stackBase[kMaxOctreeDepth * 256];
-    __shared__ uint32_t stackMask[kMaxOctreeDepth * 256];
-    __shared__ unsigned long long profile[STATS ? 32 : 1];   // 8 accumulators per wave (instrumented kernel only)
-    const uint32_t tid = threadIdx.x;
-    StackRef stk; stk.base = stackBase + tid; stk.mask = stackMask + tid; stk.prof = profile + (STATS ? 8 * (tid >> 6) : 0);
-    if (STATS) { if (tid < 32) profile[tid] = 0; __syncthreads(); }
+    const unsigned long long cyclesStart = tileCost ? __builtin_readcyclecounter() : 0ull;
+    __shared__ uint32_t stackBase[kMaxOctreeDepth * kBlockThreads];
+    __shared__ uint32_t stackMask[kMaxOctreeDepth * kBlockThreads];
+    __shared__ unsigned long long profile[8];   // section accumulators of the instrumented kernel
+    const uint32_t lane = threadIdx.x;
+    StackRef stk; stk.base = stackBase + lane; stk.mask = stackMask + lane; stk.prof = profile;
+    if (STATS) { if (lane < 8) profile[lane] = 0; __syncthreads(); }
 
-    constexpr int kBlocksPerTileSide = RT_TILE_PX / 16;                     // 16x16 pixel blocks along a tile edge
-    constexpr int kBlocksPerTile = kBlocksPerTileSide * kBlocksPerTileSide;
+    // Workgroup B runs on XCD B % 8 (round-robin dispatch).  XCD x takes the tiles at positions x, x + 8, x + 16, ... of the
+    // tile sequence: the 64 waves of a tile share one L2, and every XCD gets the same mix of cheap and expensive tiles.
     uint32_t localTile, inTile;
     if (P.blockOrder == 2) {
-        // Workgroup B runs on XCD B % 8.  XCD x takes the owned tiles x, x + 8, x + 16, ...: the 16 blocks of a tile share
-        // one L2, and every XCD gets the same mix of cheap and expensive screen regions.
         const uint32_t xcd = blockIdx.x % 8u, i = blockIdx.x / 8u;
-        localTile = (i / kBlocksPerTile) * 8u + xcd;
-        inTile = i % kBlocksPerTile;
+        localTile = (i / kWavesPerTile) * 8u + xcd;
+        inTile = i % kWavesPerTile;
         if (localTile >= (uint32_t)P.ownedTiles) {
-            if (STATS && waveClocks && (threadIdx.x & 63u) == 0) {
-                for (int k = 0; k < 10; k++) waveClocks[10 * (blockIdx.x * 4u + (threadIdx.x >> 6)) + k] = 0;
+            if (STATS && waveClocks && lane == 0) {
+                for (int k = 0; k < 10; k++) waveClocks[10 * (size_t)blockIdx.x + k] = 0;
             }
             return;
         }
     } else {
-        const uint32_t b = P.blockOrder == 1 ? xcdRemap(blockIdx.x, gridDim.x) : blockIdx.x;
-        localTile = b / kBlocksPerTile; inTile = b % kBlocksPerTile;
+        localTile = blockIdx.x / kWavesPerTile; inTile = blockIdx.x % kWavesPerTile;
     }
+    // Expensive tiles first: the slowest waves of a frame run several hundred times longer than the median, so they
+    // must not be the last to start.  tileOrder lists this rank's tiles by the cost measured on the previous frame.
+    if (tileOrder) localTile = tileOrder[localTile];
     const uint32_t tile = localTile * (uint32_t)P.world + (uint32_t)P.rank;
     const uint32_t tileX = tile % (uint32_t)P.tilesX, tileY = tile / (uint32_t)P.tilesX;
-    // wave w of the block owns the 8x8 quadrant (w & 1, w >> 1); lane l is pixel (l & 7, l >> 3) of it
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
-    const uint32_t bx = inTile % kBlocksPerTileSide, by = inTile / kBlocksPerTileSide;
-    const uint32_t lx = bx * 16u + (wave & 1u) * 8u + (lane & 7u), ly = by * 16u + (wave >> 1) * 8u + (lane >> 3);
+    // the waves of a tile walk it in Z order (neighbours in time are neighbours on screen); lane l is pixel (l & 7, l >> 3)
+    const uint32_t lx = evenBits3(inTile) * 8u + (lane & 7u), ly = evenBits3(inTile >> 1) * 8u + (lane >> 3);
     const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
 
     Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0;
@@ -766,10 +768,14 @@ __global__ __launch_bounds__(256) void renderKernel(DevScene S, FrameParams P, u
     }
 
     if (STATS && waveClocks && lane == 0) {      // diagnostic: when this wave started and finished, and its section sums
-        unsigned long long* rec = waveClocks + 10 * (blockIdx.x * 4u + wave);
+        unsigned long long* rec = waveClocks + 10 * (size_t)blockIdx.x;
         rec[0] = clockStart;
         rec[1] = __builtin_amdgcn_s_memrealtime();
         for (int k = 0; k < 8; k++) rec[2 + k] = stk.prof[k];
+    }
+    if (tileCost && lane == 0) {
+        const unsigned long long spent = __builtin_readcyclecounter() - cyclesStart;
+        atomicMax(&tileCost[localTile], (uint32_t)(spent >> 6) + 1u);   // a tile is as urgent as its slowest wave
     }
     // one atomic per wave and counter
     if (counters) {
@@ -782,6 +788,20 @@ __global__ __launch_bounds__(256) void renderKernel(DevScene S, FrameParams P, u
             if (lane == 0 && v) atomicAdd(&counters[c], (unsigned long long)v);
         }
     }
+}
+
+// order[rank of tile i by descending cost, ties by index] = i.  One thread per tile, O(n^2) comparisons: n is a few
+// hundred tiles at 1080p and 8160 at 8K.
+__global__ __launch_bounds__(256) void rankTilesKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t mine = cost[i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+        const uint32_t other = cost[j];
+        rank += (other > mine || (other == mine && j < i)) ? 1 : 0;
+    }
+    order[rank] = (uint32_t)i;
 }
 
 // Tile-major buffers of `world` ranks laid end to end -> row-major frame.  One thread per 4 output bytes.
@@ -811,17 +831,23 @@ __global__ __launch_bounds__(256) void untileKernel(const uint8_t* __restrict__ 
 // ---------------------------------------------------------------- launch wrappers (host)
 
 unsigned launchGridBlocks(const FrameParams& P) {
-    constexpr int kBlocksPerTile = (RT_TILE_PX / 16) * (RT_TILE_PX / 16);
     const int tilesLaunched = P.blockOrder == 2 ? ((P.ownedTiles + 7) / 8) * 8 : P.ownedTiles;
-    return (unsigned)(tilesLaunched * kBlocksPerTile);
+    return (unsigned)(tilesLaunched * kWavesPerTile);
 }
 
 hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
-                        unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks) {
+                        unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
+                        const uint32_t* tileOrder, uint32_t* tileCost) {
     if (P.ownedTiles <= 0) return hipSuccess;
-    dim3 grid(launchGridBlocks(P)), block(256);
-    if (stats) hipLaunchKernelGGL(renderKernel<true>, grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks);
-    else hipLaunchKernelGGL(renderKernel<false>, grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks);
+    dim3 grid(launchGridBlocks(P)), block(kBlockThreads);
+    if (stats) hipLaunchKernelGGL(renderKernel<true>, grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost);
+    else hipLaunchKernelGGL(renderKernel<false>, grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost);
+    return hipGetLastError();
+}
+
+hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, int n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rankTilesKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cost, order, n);
     return hipGetLastError();
 }
 

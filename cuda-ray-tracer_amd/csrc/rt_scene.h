@@ -11,7 +11,7 @@ namespace rt {
 
 struct OctreeParams {
     int maxDepth = 8;        // levels of internal nodes
-    int leafTriangles = 4;   // a node with at most this many triangles is a leaf
+    int leafTriangles = 8;   // a node with at most this many triangles is a leaf (8 measured best on MI355X: 4 -> +8 % frame time, 16 -> +7 %)
 };
 
 // Host staging copy of everything that goes to HBM.

@@ -119,7 +119,7 @@ int rt_count_rays(rt_ctx* ctx, int width, int height, rt_frame_stats* stats);
  * Diagnostic: renders one frame with the instrumented kernel and returns ten 64-bit words per wave of the launch:
  * [0],[1] the 100 MHz wall-clock ticks at which it started and finished (0,0 for waves of padding workgroups);
  * [2],[3] shader cycles and iterations in octree node visits; [4],[5] in triangle tests; [6],[7] in the per-model
- * gate loop; [8],[9] in stack pops.  Wave i is wave i%4 of workgroup i/4.  capacity_pairs counts waves (records).
+ * gate loop; [8],[9] unused.  Wave i is workgroup i of the launch.  capacity_pairs counts waves (records).
  * *waves_out receives the wave count.  No reference counterpart.
  */
 int rt_profile_waves(rt_ctx* ctx, int width, int height, uint64_t* clocks_out, size_t capacity_pairs, size_t* waves_out);

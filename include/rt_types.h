@@ -156,7 +156,7 @@ typedef struct rt_scene_desc {
     const rt_aabb*   AABBs;    int32_t AABBCount;
     const rt_light*  lights;   int32_t lightCount;
     const rt_model*  models;   int32_t modelCount;
-    /* Octree build parameters (0 = library default: depth 8, 4 triangles per leaf). */
+    /* Octree build parameters (0 = library default: depth 8, 8 triangles per leaf). */
     int32_t octreeMaxDepth;
     int32_t octreeLeafTriangles;
 } rt_scene_desc;
