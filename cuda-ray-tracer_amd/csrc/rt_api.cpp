@@ -67,7 +67,9 @@ struct rt_ctx {
     int blockOrder = 2;
     // Cost-ordered dispatch: per-tile cost of the previous frame and the order derived from it (device, fixed capacity
     // so that the stream entry points never allocate).  orderKey identifies the frame geometry the order belongs to.
-    uint32_t* dTileCost = nullptr; uint32_t* dTileOrder = nullptr;
+    uint32_t* dTileCost = nullptr;    // two buffers of kMaxOrderedTiles, used alternately
+    uint32_t* dTileOrder = nullptr;
+    int costSlot = 0;
     long long orderKey = -1;
     bool costOrdering = true;
 };
@@ -120,11 +122,15 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& p, uint8_t* out, int32_t* 
     }
     const long long key = ((long long)p.width << 40) ^ ((long long)p.height << 20) ^ ((long long)p.world << 8) ^ (long long)p.rank;
     const bool haveOrder = ctx->orderKey == key;
-    if (!haveOrder) RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * (size_t)p.ownedTiles, stream));
+    // Two cost buffers: this frame accumulates into `cur`; the ranking pass that follows reads it and clears `nxt`, which the
+    // next frame accumulates into.  A change of frame geometry starts over from cleared buffers and plain tile order.
+    if (!haveOrder) RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2, stream));
+    uint32_t* cur = ctx->dTileCost + (size_t)ctx->costSlot * kMaxOrderedTiles;
+    uint32_t* nxt = ctx->dTileCost + (size_t)(ctx->costSlot ^ 1) * kMaxOrderedTiles;
     RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks,
-                            haveOrder ? ctx->dTileOrder : nullptr, ctx->dTileCost));
-    RT_HIP(rt::launchRankTiles(ctx->dTileCost, ctx->dTileOrder, p.ownedTiles, stream));
-    RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * (size_t)p.ownedTiles, stream));
+                            haveOrder ? ctx->dTileOrder : nullptr, cur));
+    RT_HIP(rt::launchRankTiles(cur, ctx->dTileOrder, nxt, p.ownedTiles, stream));
+    ctx->costSlot ^= 1;
     ctx->orderKey = key;
     return RT_OK;
 }
@@ -200,8 +206,8 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     if (e != hipSuccess) { delete c; return failHip(e, "hipMalloc(counters)"); }
     c->dCounters = static_cast<unsigned long long*>(p);
     void* q = nullptr;
-    e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles);
-    if (e == hipSuccess) { c->dTileCost = static_cast<uint32_t*>(q); e = hipMemset(q, 0, sizeof(uint32_t) * kMaxOrderedTiles); }
+    e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles * 2);
+    if (e == hipSuccess) { c->dTileCost = static_cast<uint32_t*>(q); e = hipMemset(q, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2); }
     if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles); if (e == hipSuccess) c->dTileOrder = static_cast<uint32_t*>(q); }
     if (e != hipSuccess) { rt_destroy(c); return failHip(e, "hipMalloc(tile order)"); }
     e = hipEventCreate(&c->evStart);

@@ -15,8 +15,8 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
                         unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks = nullptr,
                         const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr);
 
-// order = this rank's tiles sorted by descending cost (ties by index).
-hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, int n, hipStream_t stream);
+// order = this rank's tiles sorted by descending cost (ties by index); clearNext[0..n) is zeroed for a later frame.
+hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, uint32_t* clearNext, int n, hipStream_t stream);
 
 // Workgroups (= waves) launchRender starts for these parameters.
 unsigned launchGridBlocks(const FrameParams& P);

@@ -790,18 +790,20 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevScene S, FrameP
     }
 }
 
-// order[rank of tile i by descending cost, ties by index] = i.  One thread per tile, O(n^2) comparisons: n is a few
-// hundred tiles at 1080p and 8160 at 8K.
-__global__ __launch_bounds__(256) void rankTilesKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+// order[rank of tile i by descending cost, ties by index] = i.  One wave per tile, lanes share the n comparisons
+// (n is a few hundred tiles at 1080p, 8160 at 8K).  Also clears the other cost buffer for the frame after next.
+__global__ __launch_bounds__(64) void rankTilesKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
+                                                      uint32_t* __restrict__ clearNext, int n) {
+    const int i = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
     const uint32_t mine = cost[i];
-    int rank = 0;
-    for (int j = 0; j < n; j++) {
+    uint32_t rank = 0;
+    for (int j = (int)lane; j < n; j += 64) {
         const uint32_t other = cost[j];
-        rank += (other > mine || (other == mine && j < i)) ? 1 : 0;
+        rank += (other > mine || (other == mine && j < i)) ? 1u : 0u;
     }
-    order[rank] = (uint32_t)i;
+    for (int off = 32; off > 0; off >>= 1) rank += __shfl_xor(rank, off, 64);
+    if (lane == 0) { order[rank] = (uint32_t)i; clearNext[i] = 0; }
 }
 
 // Tile-major buffers of `world` ranks laid end to end -> row-major frame.  One thread per 4 output bytes.
@@ -845,9 +847,9 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
     return hipGetLastError();
 }
 
-hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, int n, hipStream_t stream) {
+hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, uint32_t* clearNext, int n, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rankTilesKernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, cost, order, n);
+    hipLaunchKernelGGL(rankTilesKernel, dim3((unsigned)n), dim3(64), 0, stream, cost, order, clearNext, n);
     return hipGetLastError();
 }
 
