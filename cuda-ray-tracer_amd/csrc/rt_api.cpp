@@ -51,6 +51,7 @@ int uploadArray(const std::vector<T>& host, const T** devOut, std::vector<void*>
 struct rt_ctx {
     int device = 0;
     bool haveScene = false, haveState = false;
+    bool chunksSequential = true;
     rt::DevScene scene{};
     rt::FrameParams frame{};
     rt_scene_info info{};
@@ -97,6 +98,8 @@ int checkFrameArgs(rt_ctx* ctx, int width, int height) {
     if (width <= 0 || height <= 0 || width > 65536 || height > 65536) return fail(RT_ERR_INVALID, "frame size out of range");
     if (!ctx->haveScene) return fail(RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
     if (!ctx->haveState) return fail(RT_ERR_NO_STATE, "rt_update_frame_state has not been called");
+    if (ctx->frame.meshMode == rt::kMeshEightBoxes && !ctx->chunksSequential)
+        return fail(RT_ERR_INVALID, "eightBoundingBoxes needs models whose chunk boxes list their triangles in file order");
     return RT_OK;
 }
 
@@ -253,6 +256,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
         (rc = uploadArray(flat.mdlGateMin, &d.mdlGateMin, A, bytes)) || (rc = uploadArray(flat.mdlGateMax, &d.mdlGateMax, A, bytes)) ||
         (rc = uploadArray(flat.mdlTightMin, &d.mdlTightMin, A, bytes)) || (rc = uploadArray(flat.mdlTightMax, &d.mdlTightMax, A, bytes)) ||
         (rc = uploadArray(flat.mdlMat, &d.mdlMat, A, bytes)) || (rc = uploadArray(flat.mdlInfo, &d.mdlInfo, A, bytes)) ||
+        (rc = uploadArray(flat.mdlChunkMin, &d.mdlChunkMin, A, bytes)) || (rc = uploadArray(flat.mdlChunkMax, &d.mdlChunkMax, A, bytes)) ||
         (rc = uploadArray(flat.nodes, &d.nodes, A, bytes)) || (rc = uploadArray(flat.tris, &d.tris, A, bytes)) ||
         (rc = uploadArray(flat.attrs, &d.attrs, A, bytes))) {
         freeScene(ctx);
@@ -263,6 +267,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
     std::memcpy(d.lightCol, flat.lightCol, sizeof d.lightCol);
     ctx->scene = d;
     ctx->haveScene = true;
+    ctx->chunksSequential = flat.chunksSequential;
     ctx->hasSphere0 = !flat.sphGeom.empty();
     if (ctx->hasSphere0) ctx->sphere0Geom = flat.sphGeom[0];
     ctx->hasPlane0 = !flat.plnMat.empty();
@@ -302,17 +307,13 @@ int rt_update_frame_state(rt_ctx* ctx, const rt_camera* cam, const rt_config* cf
     if (cfg->specularLighting) f |= rt::kCfgSpecular;
     if (cfg->antiAliasing) f |= rt::kCfgAntiAlias;
     if (cfg->cullBackTriangles) f |= rt::kCfgCull;
-    // Mesh modes (Model.cpp:161-357).  `octree` and `boundingBox` both select the accelerated whole-model-box path:
-    // the reference's octree branch is an unfinished stub that hides every mesh, so the flag is honoured as
-    // "use the octree", which is what this library always does.  The eight-box and no-box modes are not
-    // implemented by the kernels and are rejected rather than silently rendered differently.
-    if (cfg->octree || cfg->boundingBox) {
-        if (!cfg->octree && cfg->eightBoundingBoxes) return fail(RT_ERR_INVALID, "eightBoundingBoxes mesh mode is not supported");
-        f |= rt::kCfgModelsVisible;
-    } else {
-        return fail(RT_ERR_INVALID, cfg->eightBoundingBoxes ? "eightBoundingBoxes mesh mode is not supported"
-                                                            : "mesh mode without bounding box is not supported");
-    }
+    // Mesh modes, in Model::hit's own priority order (Model.cpp:161-357).  `octree` is honoured as "whole-model box gate
+    // with the octree as accelerator": the reference's octree branch is an unfinished stub that hides every mesh.
+    if (cfg->octree) p.meshMode = rt::kMeshWholeBox;
+    else if (cfg->eightBoundingBoxes) p.meshMode = rt::kMeshEightBoxes;
+    else if (cfg->boundingBox) p.meshMode = rt::kMeshWholeBox;
+    else p.meshMode = rt::kMeshNoBox;
+    f |= rt::kCfgModelsVisible;
     p.flags = f;
 
     if (dyn && ctx->haveScene) {

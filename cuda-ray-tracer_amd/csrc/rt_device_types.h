@@ -27,8 +27,13 @@ constexpr int kMaxOctreeDepth = 12;           // levels of internal nodes the tr
 // ---- triangles ----
 // Leaf-ordered, 3 float4 per triangle: { v0.xyz, bits(id) }, { e1.xyz, 0 }, { e2.xyz, 0 } with e1 = v1 - v0 and
 // e2 = v2 - v0 computed in float on the host (the same subtraction the intersection routine starts with).
-// id = triangle index inside its model; bit 31 marks the last triangle of a leaf.
+// The id word: bits 0-26 triangle index inside its model, bits 27-29 which of the model's eight sequential chunk boxes
+// the triangle belongs to, bit 30 set if it sits in the last slot of its chunk (which the eight-box mesh mode never
+// tests), bit 31 marks the last triangle of a leaf.
 constexpr uint32_t kTriLast = 0x80000000u;
+constexpr uint32_t kTriChunkDropped = 0x40000000u;
+constexpr int kTriChunkShift = 27;
+constexpr uint32_t kTriIdMask = (1u << kTriChunkShift) - 1u;
 // Attributes for shading, 7 float4 per triangle, indexed by triBase(model) + id:
 //   { n0.xyz, ka0.x } { n1.xyz, ka0.y } { n2.xyz, ka0.z } { ka1.xyz, kd0.x } { ka2.xyz, kd0.y } { kd1.xyz, kd0.z } { kd2.xyz, 0 }
 constexpr int kAttrFloat4s = 7;
@@ -57,6 +62,8 @@ struct DevScene {
     const F4* mdlTightMin;
     const F4* mdlTightMax;
     const F4* mdlMat;          // same 3-float4 material layout
+    const F4* mdlChunkMin;     // 8 per model: the eight sequential-chunk boxes (eight-box mesh mode)
+    const F4* mdlChunkMax;
     const uint32_t* mdlInfo;   // 4 per model: { rootRef, triBase, 0, 0 }
     const F4* nodes;
     const F4* tris;
@@ -80,6 +87,7 @@ struct FrameParams {
     float background[3];
     float softRadius;
     int32_t softNum, maxDepth;
+    int32_t meshMode;          // kMesh*
     uint32_t flags;            // kCfg* bits
 };
 
@@ -88,6 +96,13 @@ enum : uint32_t {
     kCfgReflectPlanes = 1u << 4, kCfgRenderBoxes = 1u << 5, kCfgRenderModels = 1u << 6, kCfgAmbient = 1u << 7,
     kCfgDiffuse = 1u << 8, kCfgSpecular = 1u << 9, kCfgAntiAlias = 1u << 10, kCfgCull = 1u << 11,
     kCfgModelsVisible = 1u << 12   // false when the selected mesh mode renders nothing
+};
+
+// Mesh hit modes of Model::hit (Model.cpp:161-357) that render something.
+enum : int32_t {
+    kMeshWholeBox = 0,   // whole-model box gate + every triangle, t > 0 (Model.cpp:275-317)
+    kMeshEightBoxes = 1, // eight chunk-box gates, last slot of each chunk skipped, t > 0 (Model.cpp:220-274)
+    kMeshNoBox = 2       // no gate and no t > 0 test (Model.cpp:318-356)
 };
 
 // Per-launch counters (one 64-bit word each), accumulated with one atomic per wave.

@@ -223,7 +223,7 @@ RT_DEV SlabRay makeSlabRay(V3 o, V3 d) {
 
 // Four children at once: entry/exit parameters along each axis, then interval overlap with [0, tmax].
 // fmaxf/fminf drop a NaN operand (inf - inf on an axis-parallel ray), which keeps the test conservative.
-RT_DEV uint32_t testFour(f4_t nx, f4_t ny, f4_t nz, f4_t fx, f4_t fy, f4_t fz, const SlabRay& r, float tmax) {
+RT_DEV uint32_t testFour(f4_t nx, f4_t ny, f4_t nz, f4_t fx, f4_t fy, f4_t fz, const SlabRay& r, float tmin, float tmax) {
     const f2_t rx = {r.rd.x, r.rd.x}, ry = {r.rd.y, r.rd.y}, rz = {r.rd.z, r.rd.z};
     const f2_t ox = {-r.ord.x, -r.ord.x}, oy = {-r.ord.y, -r.ord.y}, oz = {-r.ord.z, -r.ord.z};
     uint32_t mask = 0;
@@ -235,7 +235,7 @@ RT_DEV uint32_t testFour(f4_t nx, f4_t ny, f4_t nz, f4_t fx, f4_t fy, f4_t fz, c
         e = __builtin_elementwise_fma(e, rx, ox); f = __builtin_elementwise_fma(f, ry, oy); g = __builtin_elementwise_fma(g, rz, oz);
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            float tn = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], 0.0f));
+            float tn = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], tmin));
             float tf = fminf(fminf(e[k], f[k]), fminf(g[k], tmax));
             mask |= (tn <= tf) ? (1u << (2 * h + k)) : 0u;
         }
@@ -244,22 +244,22 @@ RT_DEV uint32_t testFour(f4_t nx, f4_t ny, f4_t nz, f4_t fx, f4_t fy, f4_t fz, c
 }
 
 // Conservative slab test of the eight child boxes of one node; returns the bit mask of children whose box overlaps
-// [0, tmax] along the ray.  Conservative because the host pads every child box by more than the worst-case error of
+// [tmin, tmax] along the ray (tmin is 0, or -inf for the mesh mode without a t > 0 test).  Conservative because the host pads every child box by more than the worst-case error of
 // the fma / reciprocal form for coordinates and ray origins up to a few thousand units (rt_scene.cpp).
-RT_DEV uint32_t testChildren(const F4* node, const SlabRay& r, float tmax) {
+RT_DEV uint32_t testChildren(const F4* node, const SlabRay& r, float tmin, float tmax) {
     const F4* nX = node + r.nearX; const F4* fX = node + (6 - r.nearX);
     const F4* nY = node + r.nearY; const F4* fY = node + (10 - r.nearY);
     const F4* nZ = node + r.nearZ; const F4* fZ = node + (14 - r.nearZ);
-    uint32_t lo4 = testFour(ld4(nX), ld4(nY), ld4(nZ), ld4(fX), ld4(fY), ld4(fZ), r, tmax);
-    uint32_t hi4 = testFour(ld4(nX + 1), ld4(nY + 1), ld4(nZ + 1), ld4(fX + 1), ld4(fY + 1), ld4(fZ + 1), r, tmax);
+    uint32_t lo4 = testFour(ld4(nX), ld4(nY), ld4(nZ), ld4(fX), ld4(fY), ld4(fZ), r, tmin, tmax);
+    uint32_t hi4 = testFour(ld4(nX + 1), ld4(nY + 1), ld4(nZ + 1), ld4(fX + 1), ld4(fY + 1), ld4(fZ + 1), r, tmin, tmax);
     return lo4 | (hi4 << 4);
 }
 
-RT_DEV bool tightBoxHit(V3 lo, V3 hi, const SlabRay& r, float tmax) {
+RT_DEV bool tightBoxHit(V3 lo, V3 hi, const SlabRay& r, float tmin, float tmax) {
     float ax = __builtin_fmaf(lo.x, r.rd.x, -r.ord.x), bx = __builtin_fmaf(hi.x, r.rd.x, -r.ord.x);
     float ay = __builtin_fmaf(lo.y, r.rd.y, -r.ord.y), by = __builtin_fmaf(hi.y, r.rd.y, -r.ord.y);
     float az = __builtin_fmaf(lo.z, r.rd.z, -r.ord.z), bz = __builtin_fmaf(hi.z, r.rd.z, -r.ord.z);
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), 0.0f));
+    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
     float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     return tn <= tf;
 }
@@ -269,10 +269,14 @@ RT_DEV bool tightBoxHit(V3 lo, V3 hi, const SlabRay& r, float tmax) {
 //                   found earlier; among triangles of one model the lowest index wins an exact tie).
 //   ANYHIT = true : returns true as soon as some non-debug model has a triangle with 0 < t < 999.
 // skipDebug: models flagged debug are not candidates (reflection and shadow rays).
+// meshMode (kMesh*): which gates apply and whether a hit needs t > 0 - see Model.cpp:220-356.
 template <bool ANYHIT, bool STATS>
-RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug, Closest& best, StackRef stk, Counters& cnt) {
+RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, Closest& best, StackRef stk, Counters& cnt) {
     const int nMdl = S.nMdl;
     if (nMdl == 0) return false;
+    const bool positiveOnly = meshMode != kMeshNoBox;
+    const float tmin = positiveOnly ? 0.0f : -__builtin_inff();
+    uint32_t chunkMask = 0xffu;     // eight-box mode: which chunk boxes of the current model the ray passes
 
     const SlabRay sr = makeSlabRay(o, d);   // approximate arithmetic, used for the child-box tests only
     const uint32_t oct = sr.oct;
@@ -319,10 +323,12 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                             if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) continue;
                             // cheap conservative test of the triangles' own box first; the reference's gate only for
                             // rays that could reach a triangle at all - the order does not change the result
-                            if (!tightBoxHit(xyz(ld4(S.mdlTightMin + mm)), xyz(ld4(S.mdlTightMax + mm)), sr, ANYHIT ? FAR_T : best.t)) continue;
-                            if (STATS) cnt.gateTests++;
-                            float tGate;
-                            if (!boxHit(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, tGate)) continue;
+                            if (!tightBoxHit(xyz(ld4(S.mdlTightMin + mm)), xyz(ld4(S.mdlTightMax + mm)), sr, tmin, ANYHIT ? FAR_T : best.t)) continue;
+                            if (meshMode == kMeshWholeBox) {
+                                if (STATS) cnt.gateTests++;
+                                float tGate;
+                                if (!boxHit(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, tGate)) continue;
+                            }
                             gateBits |= 1ull << j;
                         }
                         if (gateBits == 0) continue;
@@ -331,9 +337,18 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                     gateBits &= gateBits - 1;
                     m = chunk + j;
                     // the closest hit may have moved in since the chunk was evaluated
-                    if (!ANYHIT && !tightBoxHit(xyz(ld4(S.mdlTightMin + m)), xyz(ld4(S.mdlTightMax + m)), sr, best.t)) continue;
+                    if (!ANYHIT && !tightBoxHit(xyz(ld4(S.mdlTightMin + m)), xyz(ld4(S.mdlTightMax + m)), sr, tmin, best.t)) continue;
                     rootRef = S.mdlInfo[4 * m];
                     if (rootRef == kNoRoot) continue;
+                    if (meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
+                        chunkMask = 0;
+                        for (int b = 0; b < 8; b++) {
+                            if (STATS) cnt.gateTests++;
+                            float tGate;
+                            if (boxHit(xyz(ld4(S.mdlChunkMin + 8 * m + b)), xyz(ld4(S.mdlChunkMax + 8 * m + b)), o, d, tGate)) chunkMask |= 1u << b;
+                        }
+                        if (chunkMask == 0) { rootRef = kNoRoot; continue; }
+                    }
                     break;
                 }
                 timerA.stop(stk, 2);
@@ -345,7 +360,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
             }
 
             const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
-            uint32_t hmask = testChildren(np, sr, ANYHIT ? FAR_T : best.t);
+            uint32_t hmask = testChildren(np, sr, tmin, ANYHIT ? FAR_T : best.t);
             u4_t meta = *reinterpret_cast<const u4_t*>(np + 14);
             uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
             if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
@@ -386,6 +401,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                 float det = dot(e1, pvec);
                 // the reference compares against the double literal -0.01; -0.01f is the smallest float that passes
                 bool rejected = (cull && det >= -0.01f) || (fabsf(det) <= 0);
+                if (meshMode == kMeshEightBoxes) rejected = rejected || (idw & kTriChunkDropped) || !((chunkMask >> ((idw >> kTriChunkShift) & 7u)) & 1u);
                 if (!rejected) {
                     float invDet = 1 / det;
                     V3 tvec = o - v0;
@@ -395,11 +411,12 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                         float v = dot(d, qvec) * invDet;
                         if (!(v < 0 || u + v > 1)) {
                             float t = dot(e2, qvec) * invDet;
-                            int id = (int)(idw & ~kTriLast);
+                            int id = (int)(idw & kTriIdMask);
+                            const bool inRange = !positiveOnly || t > 0;      // Model.cpp:287 vs :327
                             if (ANYHIT) {
-                                if (t < FAR_T && t > 0) { found = true; }
+                                if (t < FAR_T && inRange) { found = true; }
                             } else {
-                                if (t > 0 && (t < best.t || (t == best.t && id < bestTriInModel))) {
+                                if (inRange && (t < best.t || (t == best.t && id < bestTriInModel))) {
                                     best.t = t; best.kind = KIND_MODEL; best.idx = m; best.tri = id; best.u = u; best.v = v;
                                     bestTriInModel = id;
                                 }
@@ -560,7 +577,7 @@ RT_DEV bool fullShadow(const DevScene& S, const FrameParams& P, V3 so, V3 sd, St
     if (shadowBoxes(S, so, sd)) return true;
     if (!(P.flags & kCfgModelsVisible)) return false;
     Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
-    return traceModels<true, STATS>(S, so, sd, (P.flags & kCfgCull) != 0, true, dummy, stk, cnt);
+    return traceModels<true, STATS>(S, so, sd, (P.flags & kCfgCull) != 0, true, P.meshMode, dummy, stk, cnt);
 }
 
 // One camera sample: kernels.cu:224-318 with the reflection chain kernels.cu:130-222 unrolled into levels.
@@ -589,7 +606,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px
         traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h);
         if (modelsVisible) {
             // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
-            traceModels<false, STATS>(S, ro, rdir, cull, (level & 1) != 0, h, stk, cnt);
+            traceModels<false, STATS>(S, ro, rdir, cull, (level & 1) != 0, P.meshMode, h, stk, cnt);
         }
         if (level == 0) primaryOut = h;
         V3 colour = background;
@@ -631,7 +648,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px
                         hitsCount += shadowBoxes(S, biased, sd) ? 1 : 0;
                         if (P.flags & kCfgModelsVisible) {   // the shadow traces ignore renderModels (kernels.cu:304)
                             Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
-                            hitsCount += traceModels<true, STATS>(S, biased, sd, cull, true, dummy, stk, cnt) ? 1 : 0;
+                            hitsCount += traceModels<true, STATS>(S, biased, sd, cull, true, P.meshMode, dummy, stk, cnt) ? 1 : 0;
                         }
                     }
                     softFactor = 1 - ((float)hitsCount / (float)P.softNum);

@@ -129,7 +129,7 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
     const uint32_t triBase = (uint32_t)(out.attrs.size() / kAttrFloat4s);
 
     if (nTri > 0 && (!m.vertices || !m.indices)) { err = "model " + std::to_string(modelIndex) + ": null vertex or index array"; return false; }
-    if (nTri >= (int64_t)kTriLast) { err = "model " + std::to_string(modelIndex) + ": too many triangles"; return false; }
+    if (nTri > (int64_t)kTriIdMask) { err = "model " + std::to_string(modelIndex) + ": too many triangles"; return false; }
 
     std::vector<BuildTri> btris((size_t)nTri);
     Box tight;
@@ -168,6 +168,28 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
         out.attrs.insert(out.attrs.end(), rec, rec + kAttrFloat4s);
     }
 
+    // Chunk membership for the eight-box mode (Model.cpp:62-84): triangle t sits in chunk t / perBox at slot t % perBox, and
+    // the reference's loop over a chunk stops one slot short of its end.  This only holds if the caller's chunk index
+    // lists are the sequential deal of `indices` that the reference constructor produces; remember if they are not.
+    const int64_t perBoxTris = (int64_t)std::ceil((double)(m.indicesCount / 3) / 8.0);
+    std::vector<uint32_t> chunkTag((size_t)nTri, 0u);
+    for (int64_t t = 0; t < nTri; t++) {
+        const int64_t b = perBoxTris > 0 ? t / perBoxTris : 0, slot = perBoxTris > 0 ? t % perBoxTris : 0;
+        bool ok = b < 8 && m.boundingBoxes[b].includedModelIndices && (int64_t)m.boundingBoxes[b].indicesCount >= 3 * (slot + 1);
+        if (ok) {
+            const int32_t* ci = m.boundingBoxes[b].includedModelIndices + 3 * slot;
+            const int32_t* ix = m.indices + 3 * t;
+            ok = ci[0] == ix[0] && ci[1] == ix[1] && ci[2] == ix[2];
+        }
+        if (!ok) { out.chunksSequential = false; break; }
+        const bool lastSlot = 3 * (slot + 1) >= (int64_t)m.boundingBoxes[b].indicesCount;   // for (j = 0; j < indicesCount - 3; j += 3) never reaches it
+        chunkTag[(size_t)t] = ((uint32_t)b << kTriChunkShift) | (lastSlot ? kTriChunkDropped : 0u);
+    }
+    for (int b = 0; b < 8; b++) {
+        out.mdlChunkMin.push_back(f4(m.boundingBoxes[b].min, 0.0f));
+        out.mdlChunkMax.push_back(f4(m.boundingBoxes[b].max, 0.0f));
+    }
+
     // Child boxes are padded so that the approximate slab test of the traversal can never reject a box whose
     // triangle the exact intersection routine would accept.
     const float pad = std::max(1e-3f, 4e-6f * maxAbs);
@@ -184,7 +206,7 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
             const rt_vec3& p0 = m.vertices[ix[0]].position;
             const rt_vec3& p1 = m.vertices[ix[1]].position;
             const rt_vec3& p2 = m.vertices[ix[2]].position;
-            uint32_t id = (uint32_t)ids[i] | (i + 1 == ids.size() ? kTriLast : 0u);
+            uint32_t id = (uint32_t)ids[i] | chunkTag[(size_t)ids[i]] | (i + 1 == ids.size() ? kTriLast : 0u);
             out.tris.push_back(f4(p0.x, p0.y, p0.z, bitsFloat(id)));
             out.tris.push_back(f4(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, 0.0f));   // Model.cpp:137
             out.tris.push_back(f4(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z, 0.0f));   // Model.cpp:138
@@ -323,7 +345,7 @@ struct Walker {
         for (uint32_t t = start;; t++) {
             if ((size_t)t * 3 + 2 >= flat.tris.size()) { err = "leaf runs past the triangle array"; return false; }
             uint32_t idw; std::memcpy(&idw, &flat.tris[(size_t)t * 3].w, 4);
-            uint32_t id = idw & ~kTriLast;
+            uint32_t id = idw & kTriIdMask;
             if (id >= seen.size()) { err = "triangle id out of range"; return false; }
             if (seen[id]) { err = "triangle " + std::to_string(id) + " appears in two leaves"; return false; }
             seen[id] = 1;

@@ -270,7 +270,7 @@ static int model_hit(const rt_model* m, v3 o, v3 d, float* t0, hit_vertex* hv,
                 if (tClosest != FAR_T) {
                     if (tClosest < bestT) {
                         bestT = tClosest;
-                        fill_hit_vertex(m, w0, w1, w2, u, v, b * (1 << 24) + wj / 3, &best);
+                        fill_hit_vertex(m, w0, w1, w2, u, v, b * (bb->indicesCount / 3) + wj / 3, &best);
                     }
                 }
             }

@@ -218,8 +218,44 @@ def test_errors_are_reported_not_swallowed(pkg):
         r.upload(built.desc)
         with pytest.raises(binding.RtError):
             r.render(64, 64)                       # no frame state yet
-        cfg.boundingBox = 0
+        cfg.softShadowNum = -1
         with pytest.raises(binding.RtError):
-            r.set_state(built.camera, cfg)         # unsupported mesh mode
+            r.set_state(built.camera, cfg)         # invalid configuration
     finally:
         r.close()
+
+
+@pytest.mark.parametrize("mode", ["eight", "none"])
+@pytest.mark.parametrize("scene", ["cfg2", "cfg3", "period"])
+def test_other_mesh_modes_match_the_oracle(renderer, oracle, mode, scene):
+    """Model::hit's eight-chunk-box mode (Model.cpp:220-274) and its mode without any box or t > 0 test (:318-356)."""
+    if scene == "cfg2":
+        spec, cfg, _, _ = scenes.config_scene(2, detail=0.4)
+    elif scene == "cfg3":
+        spec, cfg, _, _ = scenes.config_scene(3, detail=0.15)
+    else:
+        index, cfg = scenes.preset_config(".")
+        spec = scenes.reference_scene(index, detail=0.4)
+        scenes.apply_frame_fixups(spec, cfg)
+    if mode == "eight":
+        cfg.eightBoundingBoxes = 1
+    else:
+        cfg.boundingBox = 0
+    stats, st, o_rays = _run(renderer, oracle, spec, cfg, 256, 144)
+    print(mode, scene, stats, st.rays)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0
+
+
+def test_octree_flag_renders_meshes_with_whole_box_semantics(renderer, oracle):
+    """Deliberate deviation: config.octree hides every mesh in the reference (unfinished stub); here it selects the
+    octree-accelerated whole-box mode, i.e. the same pixels as boundingBox = true."""
+    spec, cfg, _, _ = scenes.config_scene(2, detail=0.3)
+    built = scenes.build_scene(spec)
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    base, _ = renderer.render(192, 108)
+    cfg.octree = 1; cfg.boundingBox = 0; cfg.eightBoundingBoxes = 1
+    renderer.set_state(built.camera, cfg)
+    flagged, _ = renderer.render(192, 108)
+    assert np.array_equal(base, flagged)
