@@ -389,10 +389,13 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
             uint32_t c = k ^ oct;
             uint32_t start = c == 0 ? lr0 : c == 1 ? lr1 : c == 2 ? lr2 : c == 3 ? lr3 : c == 4 ? lr4 : c == 5 ? lr5 : c == 6 ? lr6 : lr7;
             const F4* tp = S.tris + (size_t)start * 3;
+            // software pipeline: the next record is requested before the current one is intersected (the triangle array ends
+            // with one spare record, so reading one past the leaf is always in bounds)
+            f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
             for (;;) {
                 SectionTimer<STATS> timerB;
-                f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
                 tp += 3;
+                const f4_t nA = ld4(tp), nB = ld4(tp + 1), nC = ld4(tp + 2);
                 uint32_t idw = fbits(A.w);
                 if (STATS) cnt.triTests++;
                 // Moeller-Trumbore exactly as the reference evaluates it (edges were subtracted on the host)
@@ -426,6 +429,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                 }
                 timerB.stop(stk, 1);
                 if ((idw & kTriLast) || (ANYHIT && found)) break;
+                A = nA; B = nB; C = nC;
             }
             if (ANYHIT && found) { pend = 0; done = true; hits = 0; sp = 0; }
         }

@@ -324,7 +324,30 @@ def config_scene(number, detail=1.0):
                        ModelSpec("Crown", (12.0, -10.0, -8.0), 8, shiny, False, T.RT_REFLECT, detail),
                        ModelSpec("Book2_Open", (-10.0, -10.0, 10.0), 10, d, False, T.RT_DIFFUSE, detail)]
         w, h = 3840, 2160
+    elif number == 5:   # field of baked copies (the reference has no instancing) of Chicken and WoodLog, ~10 M triangles at detail 8
+        cfg = default_config(); cfg.renderHardShadows = 1; cfg.reflections = 1; cfg.reflectPlanes = 1
+        spec = SceneSpec(planes=[_floor()], light=(-60.0, -160.0, 120.0), spheres=[_marker((-60.0, -160.0, 120.0))],
+                         cam_pos=(0.0, -70.0, 260.0), cam_yaw=-90.0, cam_pitch=14.0)
+        matte = ((1.0, 0.0, 0.0), (1.0, 0.0, 0.0), 0.1, 0.9, 0.2, 20.0)
+        n = 12
+        for i in range(n):
+            for j in range(n):
+                name = "Chicken" if (i + j) % 2 == 0 else "WoodLog"
+                x = (j - (n - 1) / 2.0) * 34.0
+                z = 120.0 - i * 34.0
+                spec.models.append(ModelSpec(name, (x, 20.0, z), 14, matte, False, T.RT_DIFFUSE, detail))
+        w, h = 7680, 4320
     else:
-        raise ValueError("configuration 1..4")
+        raise ValueError("configuration 1..5")
     apply_frame_fixups(spec, cfg)
     return spec, cfg, w, h
+
+
+def camera_path_pose(spec, frame, frames=120):
+    """The fixed camera path of the 120-frame benchmark: a yaw sweep of +-12 degrees with a slow dolly towards the scene.
+    Returns (position, yaw, pitch) for `frame`."""
+    import math
+    u = frame / max(frames - 1, 1)
+    yaw = spec.cam_yaw + 12.0 * math.sin(2.0 * math.pi * u)
+    pos = (spec.cam_pos[0] + 20.0 * math.sin(2.0 * math.pi * u), spec.cam_pos[1], spec.cam_pos[2] - 40.0 * u)
+    return pos, yaw, spec.cam_pitch
