@@ -263,6 +263,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
         return rc;
     }
     d.nSph = scene->sphereCount; d.nPln = scene->planeCount; d.nBox = scene->AABBCount; d.nMdl = scene->modelCount;
+    d.forestRoot = flat.forestRoot;
     std::memcpy(d.lightPos, flat.lightPos, sizeof d.lightPos);
     std::memcpy(d.lightCol, flat.lightCol, sizeof d.lightCol);
     ctx->scene = d;

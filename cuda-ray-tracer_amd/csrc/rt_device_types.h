@@ -14,18 +14,25 @@ namespace rt {
 //   f4[2..3]  lo.y                           f4[8..9]   hi.y
 //   f4[4..5]  lo.z                           f4[10..11] hi.z
 //   u4[12..13] leafRef[8]: first triangle of a leaf child in the leaf-ordered triangle array
-//   u4[14]    { childBase, internalMask | leafMask << 8, 0, 0 }
+//   u4[14]    { childBase, internalMask | leafMask << 8, model, 0 }
 //   u4[15]    unused
 // Internal children are stored contiguously from childBase in slot order, so child slot c is node
 // childBase + popcount(internalMask & ((1 << c) - 1)).  Empty slots hold an inverted box (lo = +inf, hi = -inf).
 // Slot c is the octant (x > cx) | (y > cy) << 1 | (z > cz) << 2 of the node's split point.
+//
+// All models hang off one forest: nodes above the models group model roots by position, and the root node of a model's
+// own octree carries the model's index in `model` (kNoModel everywhere else).  The traversal evaluates the model's
+// exact bounding-box gate when it reaches such a node.  A scene with a single non-empty model has that model's root as
+// the forest root.
 constexpr int kNodeFloat4s = 16;
-constexpr uint32_t kLeafFlag = 0x80000000u;   // in a model's root reference: the root is a leaf
-constexpr uint32_t kNoRoot = 0xFFFFFFFFu;     // model without triangles
-constexpr int kMaxOctreeDepth = 12;           // levels of internal nodes the traversal stack can hold
+constexpr uint32_t kNoRoot = 0xFFFFFFFFu;     // model without triangles / scene without mesh triangles
+constexpr uint32_t kNoModel = 0xFFFFFFFFu;
+constexpr int kMaxOctreeDepth = 16;           // nesting levels (forest + model octree) the traversal stack can hold
+constexpr int kMaxModelOctreeDepth = 10;      // cap on the per-model build depth
+constexpr int kPregatedModels = 64;           // up to this many models the gates are evaluated once per ray, up front
 
 // ---- triangles ----
-// Leaf-ordered, 3 float4 per triangle: { v0.xyz, bits(id) }, { e1.xyz, 0 }, { e2.xyz, 0 } with e1 = v1 - v0 and
+// Leaf-ordered, 3 float4 per triangle: { v0.xyz, bits(id) }, { e1.xyz, bits(model) }, { e2.xyz, 0 } with e1 = v1 - v0 and
 // e2 = v2 - v0 computed in float on the host (the same subtraction the intersection routine starts with).
 // The id word: bits 0-26 triangle index inside its model, bits 27-29 which of the model's eight sequential chunk boxes
 // the triangle belongs to, bit 30 set if it sits in the last slot of its chunk (which the eight-box mesh mode never
@@ -64,11 +71,12 @@ struct DevScene {
     const F4* mdlMat;          // same 3-float4 material layout
     const F4* mdlChunkMin;     // 8 per model: the eight sequential-chunk boxes (eight-box mesh mode)
     const F4* mdlChunkMax;
-    const uint32_t* mdlInfo;   // 4 per model: { rootRef, triBase, 0, 0 }
+    const uint32_t* mdlInfo;   // 4 per model: { root node (kNoRoot if empty), triBase, 0, 0 }
     const F4* nodes;
     const F4* tris;
     const F4* attrs;
     int32_t nSph, nPln, nBox, nMdl;
+    uint32_t forestRoot;       // node the mesh traversal starts from, kNoRoot if no model has a reachable triangle
     float lightPos[3];
     float lightCol[3];
 };

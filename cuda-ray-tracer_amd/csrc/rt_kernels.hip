@@ -265,15 +265,16 @@ RT_DEV bool tightBoxHit(V3 lo, V3 hi, const SlabRay& r, float tmin, float tmax) 
 }
 
 // Traces (o, d) against every eligible model.
-//   ANYHIT = false: closest hit, merged into `best` with the reference's tie rules (strictly nearer than anything
-//                   found earlier; among triangles of one model the lowest index wins an exact tie).
+//   ANYHIT = false: closest hit, merged into `best` (which must not hold a model hit yet) with the reference's tie rules:
+//                   strictly nearer than any other kind of object found earlier; among triangles an exact tie goes to
+//                   the lower model index, then the lower triangle index.
 //   ANYHIT = true : returns true as soon as some non-debug model has a triangle with 0 < t < 999.
 // skipDebug: models flagged debug are not candidates (reflection and shadow rays).
 // meshMode (kMesh*): which gates apply and whether a hit needs t > 0 - see Model.cpp:220-356.
 template <bool ANYHIT, bool STATS>
 RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, Closest& best, StackRef stk, Counters& cnt) {
+    if (S.forestRoot == kNoRoot) return false;
     const int nMdl = S.nMdl;
-    if (nMdl == 0) return false;
     const bool positiveOnly = meshMode != kMeshNoBox;
     const float tmin = positiveOnly ? 0.0f : -__builtin_inff();
     uint32_t chunkMask = 0xffu;     // eight-box mode: which chunk boxes of the current model the ray passes
@@ -281,87 +282,73 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
     const SlabRay sr = makeSlabRay(o, d);   // approximate arithmetic, used for the child-box tests only
     const uint32_t oct = sr.oct;
 
-    int m = -1;                 // current model
-    int chunk = -64;            // first model of the 64-model chunk whose gate bits are in gateBits
+    // Is model mm a candidate for this ray at all: not hidden from this ray type, and (whole-box mode) through the
+    // reference's exact bounding-box gate.
+    auto gate = [&](int mm) -> bool {
+        if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) return false;
+        if (meshMode == kMeshWholeBox) {
+            if (STATS) cnt.gateTests++;
+            float tGate;
+            return boxHit(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, tGate);
+        }
+        return true;
+    };
+
+    // Small scenes: evaluate every gate up front.  All lanes run the same trip count here, so the exact gate (six
+    // divisions per model) is not serialised across lanes the way it is when each lane meets a model root at its own
+    // time.  The cheap conservative test of the triangles' own box comes first; the order does not change the result.
+    const bool pregated = nMdl <= kPregatedModels;
     unsigned long long gateBits = 0;
-    int bestTriInModel = 0x7fffffff;   // id of the current best hit if it lies in model m, else "none"
-    uint32_t base = 0, imask = 0, hits = 0;   // children still to visit below the current node
+    if (pregated) {
+        SectionTimer<STATS> timerG;
+        for (int j = 0; j < nMdl; j++) {
+            if (!tightBoxHit(xyz(ld4(S.mdlTightMin + j)), xyz(ld4(S.mdlTightMax + j)), sr, tmin, ANYHIT ? FAR_T : best.t)) continue;
+            if (gate(j)) gateBits |= 1ull << j;
+        }
+        timerG.stop(stk, 2);
+        if (gateBits == 0) return false;
+    }
+
+    // children still to visit below the current node; the start state is one pseudo child that resolves to the forest root
+    uint32_t base = S.forestRoot, imask = 0, hits = 1;
     int sp = 0;
     uint32_t pend = 0;          // leaf children still to intersect (permuted order)
     uint32_t lr0 = 0, lr1 = 0, lr2 = 0, lr3 = 0, lr4 = 0, lr5 = 0, lr6 = 0, lr7 = 0;
-    bool done = false, found = false;
+    bool found = false;
 
     for (;;) {
-        // ---- descend until this lane has triangles to test or has run out of models
-        while (!done && pend == 0) {
+        // ---- descend until this lane has triangles to test or has nothing left to visit
+        while (pend == 0) {
             SectionTimer<STATS> timerA;
-            if (hits == 0 && sp > 0) {      // siblings left on an upper level
-                sp--;
+            if (hits == 0) {
+                if (sp == 0) break;
+                sp--;                       // siblings left on an upper level
                 base = stk.base[sp * kBlockThreads];
                 uint32_t packed = stk.mask[sp * kBlockThreads];
                 imask = packed & 0xffu;
                 hits = packed >> 8;
             }
-            uint32_t node;
-            if (hits != 0) {
-                uint32_t k = __builtin_ctz(hits);
-                hits &= hits - 1;
-                uint32_t c = k ^ oct;
-                node = base + __builtin_popcount(imask & ((1u << c) - 1u));
-            } else {
-                // next model the ray can reach: bit set in gateBits, tight box still within range
-                uint32_t rootRef = kNoRoot;
-                for (;;) {
-                    if (gateBits == 0) {
-                        // Evaluate a whole chunk of models at once: every lane that gets here runs the same trip count, so
-                        // the expensive exact gate (six divisions per model) is not serialised across lanes.
-                        chunk += 64;
-                        if (chunk >= nMdl) break;
-                        const int end = (nMdl - chunk) < 64 ? (nMdl - chunk) : 64;
-                        for (int j = 0; j < end; j++) {
-                            const int mm = chunk + j;
-                            if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) continue;
-                            // cheap conservative test of the triangles' own box first; the reference's gate only for
-                            // rays that could reach a triangle at all - the order does not change the result
-                            if (!tightBoxHit(xyz(ld4(S.mdlTightMin + mm)), xyz(ld4(S.mdlTightMax + mm)), sr, tmin, ANYHIT ? FAR_T : best.t)) continue;
-                            if (meshMode == kMeshWholeBox) {
-                                if (STATS) cnt.gateTests++;
-                                float tGate;
-                                if (!boxHit(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, tGate)) continue;
-                            }
-                            gateBits |= 1ull << j;
-                        }
-                        if (gateBits == 0) continue;
-                    }
-                    const int j = __builtin_ctzll(gateBits);
-                    gateBits &= gateBits - 1;
-                    m = chunk + j;
-                    // the closest hit may have moved in since the chunk was evaluated
-                    if (!ANYHIT && !tightBoxHit(xyz(ld4(S.mdlTightMin + m)), xyz(ld4(S.mdlTightMax + m)), sr, tmin, best.t)) continue;
-                    rootRef = S.mdlInfo[4 * m];
-                    if (rootRef == kNoRoot) continue;
-                    if (meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
-                        chunkMask = 0;
-                        for (int b = 0; b < 8; b++) {
-                            if (STATS) cnt.gateTests++;
-                            float tGate;
-                            if (boxHit(xyz(ld4(S.mdlChunkMin + 8 * m + b)), xyz(ld4(S.mdlChunkMax + 8 * m + b)), o, d, tGate)) chunkMask |= 1u << b;
-                        }
-                        if (chunkMask == 0) { rootRef = kNoRoot; continue; }
-                    }
-                    break;
-                }
-                timerA.stop(stk, 2);
-                if (rootRef == kNoRoot) { done = true; break; }
-                timerA = SectionTimer<STATS>();
-                bestTriInModel = 0x7fffffff;
-                if (rootRef & kLeafFlag) { pend = 1u; lr0 = rootRef & ~kLeafFlag; lr1 = lr0; lr2 = lr0; lr3 = lr0; lr4 = lr0; lr5 = lr0; lr6 = lr0; lr7 = lr0; break; }
-                node = rootRef;
-            }
+            uint32_t k = __builtin_ctz(hits);
+            hits &= hits - 1;
+            uint32_t c = k ^ oct;
+            const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
 
             const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
-            uint32_t hmask = testChildren(np, sr, tmin, ANYHIT ? FAR_T : best.t);
             u4_t meta = *reinterpret_cast<const u4_t*>(np + 14);
+            if (meta.z != kNoModel) {       // root of a model's octree
+                const int mm = (int)meta.z;
+                if (pregated ? !((gateBits >> mm) & 1ull) : !gate(mm)) continue;
+                if (meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
+                    chunkMask = 0;
+                    for (int b = 0; b < 8; b++) {
+                        if (STATS) cnt.gateTests++;
+                        float tGate;
+                        if (boxHit(xyz(ld4(S.mdlChunkMin + 8 * mm + b)), xyz(ld4(S.mdlChunkMax + 8 * mm + b)), o, d, tGate)) chunkMask |= 1u << b;
+                    }
+                    if (chunkMask == 0) continue;
+                }
+            }
+            uint32_t hmask = testChildren(np, sr, tmin, ANYHIT ? FAR_T : best.t);
             uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
             if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
             if (hits != 0) {   // keep the siblings that are still waiting
@@ -380,7 +367,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
             }
             timerA.stop(stk, 0);
         }
-        if (pend == 0) break;   // done
+        if (pend == 0) break;   // nothing left
 
         // ---- intersect the triangles of the pending leaves
         while (pend != 0) {
@@ -414,14 +401,15 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                         float v = dot(d, qvec) * invDet;
                         if (!(v < 0 || u + v > 1)) {
                             float t = dot(e2, qvec) * invDet;
-                            int id = (int)(idw & kTriIdMask);
+                            const int id = (int)(idw & kTriIdMask), mm = (int)fbits(B.w);
                             const bool inRange = !positiveOnly || t > 0;      // Model.cpp:287 vs :327
                             if (ANYHIT) {
                                 if (t < FAR_T && inRange) { found = true; }
                             } else {
-                                if (inRange && (t < best.t || (t == best.t && id < bestTriInModel))) {
-                                    best.t = t; best.kind = KIND_MODEL; best.idx = m; best.tri = id; best.u = u; best.v = v;
-                                    bestTriInModel = id;
+                                // an exact tie goes to the triangle the reference's loops meet first: lower model, then lower index
+                                const bool earlier = best.kind == KIND_MODEL && (mm < best.idx || (mm == best.idx && id < best.tri));
+                                if (inRange && (t < best.t || (t == best.t && earlier))) {
+                                    best.t = t; best.kind = KIND_MODEL; best.idx = mm; best.tri = id; best.u = u; best.v = v;
                                 }
                             }
                         }
@@ -431,7 +419,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                 if ((idw & kTriLast) || (ANYHIT && found)) break;
                 A = nA; B = nB; C = nC;
             }
-            if (ANYHIT && found) { pend = 0; done = true; hits = 0; sp = 0; }
+            if (ANYHIT && found) { pend = 0; hits = 0; sp = 0; }
         }
         if (ANYHIT && found) break;
     }

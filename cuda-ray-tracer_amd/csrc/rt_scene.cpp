@@ -123,38 +123,62 @@ void packMaterial(const rt_material& m, int objectType, uint32_t flags, F4 out[3
 
 static bool isIgnoredPosition(const rt_vec3& p) { return p.x == -999.0f && p.y == -999.0f && p.z == -999.0f; }
 
-// Emits the octree and triangle records of one model into the shared arrays.
-static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& params, FlatScene& out, std::string& err) {
+// Writes one 256-byte node record.
+static void writeNode(F4* rec, const float lo[3][8], const float hi[3][8], const uint32_t leafRef[8], uint32_t childBase,
+                      uint32_t imask, uint32_t lmask, uint32_t model) {
+    for (int a = 0; a < 3; a++) {
+        rec[2 * a + 0] = f4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
+        rec[2 * a + 1] = f4(lo[a][4], lo[a][5], lo[a][6], lo[a][7]);
+        rec[6 + 2 * a + 0] = f4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
+        rec[6 + 2 * a + 1] = f4(hi[a][4], hi[a][5], hi[a][6], hi[a][7]);
+    }
+    rec[12] = f4(bitsFloat(leafRef[0]), bitsFloat(leafRef[1]), bitsFloat(leafRef[2]), bitsFloat(leafRef[3]));
+    rec[13] = f4(bitsFloat(leafRef[4]), bitsFloat(leafRef[5]), bitsFloat(leafRef[6]), bitsFloat(leafRef[7]));
+    rec[14] = f4(bitsFloat(childBase), bitsFloat(imask | (lmask << 8)), bitsFloat(model), 0.0f);
+    rec[15] = f4(0.0f, 0.0f, 0.0f, 0.0f);
+}
+
+// Validates a model's arrays and returns the bounds of its reachable triangles and the padding of its child boxes.
+// Child boxes are padded so that the approximate slab test of the traversal can never reject a box whose
+// triangle the exact intersection routine would accept.
+static bool modelBounds(const rt_model& m, int modelIndex, Box& tight, float& pad, std::string& err) {
+    const int64_t nTri = reachableTriangles(m.indicesCount);
+    if (nTri > 0 && (!m.vertices || !m.indices)) { err = "model " + std::to_string(modelIndex) + ": null vertex or index array"; return false; }
+    if (nTri > (int64_t)kTriIdMask) { err = "model " + std::to_string(modelIndex) + ": too many triangles"; return false; }
+    float maxAbs = 0.0f;
+    for (int64_t i = 0; i < 3 * nTri; i++) {
+        const int32_t ix = m.indices[i];
+        if (ix < 0 || ix >= m.vertCount) { err = "model " + std::to_string(modelIndex) + ": index out of range"; return false; }
+        const rt_vec3& p = m.vertices[ix].position;
+        if (!finite3(p)) { err = "model " + std::to_string(modelIndex) + ": non-finite vertex position"; return false; }
+        const float pp[3] = {p.x, p.y, p.z};
+        tight.grow(pp);
+        maxAbs = std::max(maxAbs, std::max(std::fabs(p.x), std::max(std::fabs(p.y), std::fabs(p.z))));
+    }
+    pad = std::max(1e-3f, 4e-6f * maxAbs);
+    return true;
+}
+
+// Emits the octree and triangle records of one model into the shared arrays.  `rootIndex` is the node the forest
+// reserved for the model's root (unused for a model without reachable triangles); `tight` / `pad` come from modelBounds.
+static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& params, uint32_t rootIndex, const Box& tight,
+                         float pad, FlatScene& out, std::string& err) {
     const int64_t nTri = reachableTriangles(m.indicesCount);
     const uint32_t triBase = (uint32_t)(out.attrs.size() / kAttrFloat4s);
 
-    if (nTri > 0 && (!m.vertices || !m.indices)) { err = "model " + std::to_string(modelIndex) + ": null vertex or index array"; return false; }
-    if (nTri > (int64_t)kTriIdMask) { err = "model " + std::to_string(modelIndex) + ": too many triangles"; return false; }
-
+    (void)err;
     std::vector<BuildTri> btris((size_t)nTri);
-    Box tight;
-    float maxAbs = 0.0f;
     for (int64_t t = 0; t < nTri; t++) {
         const int32_t* ix = m.indices + 3 * t;
-        for (int k = 0; k < 3; k++) {
-            if (ix[k] < 0 || ix[k] >= m.vertCount) { err = "model " + std::to_string(modelIndex) + ": index out of range"; return false; }
-        }
         const rt_vertex& a = m.vertices[ix[0]];
         const rt_vertex& b = m.vertices[ix[1]];
         const rt_vertex& c = m.vertices[ix[2]];
-        if (!finite3(a.position) || !finite3(b.position) || !finite3(c.position)) {
-            err = "model " + std::to_string(modelIndex) + ": non-finite vertex position"; return false;
-        }
         BuildTri& bt = btris[(size_t)t];
         const float pa[3] = {a.position.x, a.position.y, a.position.z};
         const float pb[3] = {b.position.x, b.position.y, b.position.z};
         const float pc[3] = {c.position.x, c.position.y, c.position.z};
         bt.box.grow(pa); bt.box.grow(pb); bt.box.grow(pc);
-        for (int ax = 0; ax < 3; ax++) {
-            bt.centre[ax] = 0.5f * bt.box.lo[ax] + 0.5f * bt.box.hi[ax];
-            maxAbs = std::max(maxAbs, std::max(std::fabs(bt.box.lo[ax]), std::fabs(bt.box.hi[ax])));
-        }
-        tight.grow(bt.box);
+        for (int ax = 0; ax < 3; ax++) bt.centre[ax] = 0.5f * bt.box.lo[ax] + 0.5f * bt.box.hi[ax];
 
         // shading attributes, original triangle order
         F4 rec[kAttrFloat4s];
@@ -190,10 +214,6 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
         out.mdlChunkMax.push_back(f4(m.boundingBoxes[b].max, 0.0f));
     }
 
-    // Child boxes are padded so that the approximate slab test of the traversal can never reject a box whose
-    // triangle the exact intersection routine would accept.
-    const float pad = std::max(1e-3f, 4e-6f * maxAbs);
-
     OctreeBuilder builder(btris, params);
     int root = builder.build();
 
@@ -208,7 +228,7 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
             const rt_vec3& p2 = m.vertices[ix[2]].position;
             uint32_t id = (uint32_t)ids[i] | chunkTag[(size_t)ids[i]] | (i + 1 == ids.size() ? kTriLast : 0u);
             out.tris.push_back(f4(p0.x, p0.y, p0.z, bitsFloat(id)));
-            out.tris.push_back(f4(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, 0.0f));   // Model.cpp:137
+            out.tris.push_back(f4(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, bitsFloat((uint32_t)modelIndex)));   // Model.cpp:137
             out.tris.push_back(f4(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z, 0.0f));   // Model.cpp:138
         }
         out.leafCount++;
@@ -218,16 +238,20 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
     uint32_t rootRef = kNoRoot;
     if (root >= 0) {
         const std::vector<TreeNode>& T = builder.nodes;
+        const float inf = std::numeric_limits<float>::infinity();
+        rootRef = rootIndex;
         if (T[root].leaf) {
-            rootRef = kLeafFlag | emitLeaf(T[root]);
+            // a model small enough for one leaf still gets a root node, with that leaf as its only child
+            float lo[3][8], hi[3][8];
+            uint32_t leafRef[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int c = 0; c < 8; c++) for (int a = 0; a < 3; a++) { lo[a][c] = inf; hi[a][c] = -inf; }
+            for (int a = 0; a < 3; a++) { lo[a][0] = tight.lo[a] - pad; hi[a][0] = tight.hi[a] + pad; }
+            leafRef[0] = emitLeaf(T[root]);
+            writeNode(&out.nodes[(size_t)rootIndex * kNodeFloat4s], lo, hi, leafRef, 0u, 0u, 1u, (uint32_t)modelIndex);
         } else {
             // breadth-first flattening: (tree node, flat node index)
             std::vector<std::pair<int, uint32_t>> queue;
-            uint32_t flatRoot = (uint32_t)(out.nodes.size() / kNodeFloat4s);
-            out.nodes.resize(out.nodes.size() + kNodeFloat4s);
-            queue.emplace_back(root, flatRoot);
-            rootRef = flatRoot;
-            const float inf = std::numeric_limits<float>::infinity();
+            queue.emplace_back(root, rootIndex);
             for (size_t q = 0; q < queue.size(); q++) {
                 const TreeNode& n = T[queue[q].first];
                 const uint32_t self = queue[q].second;
@@ -249,20 +273,11 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
                     if (ch.leaf) { lmask |= 1u << c; leafRef[c] = emitLeaf(ch); }
                     else { imask |= 1u << c; queue.emplace_back(n.child[c], next++); }
                 }
-                F4* rec = &out.nodes[(size_t)self * kNodeFloat4s];
-                for (int a = 0; a < 3; a++) {
-                    rec[2 * a + 0] = f4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
-                    rec[2 * a + 1] = f4(lo[a][4], lo[a][5], lo[a][6], lo[a][7]);
-                    rec[6 + 2 * a + 0] = f4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
-                    rec[6 + 2 * a + 1] = f4(hi[a][4], hi[a][5], hi[a][6], hi[a][7]);
-                }
-                rec[12] = f4(bitsFloat(leafRef[0]), bitsFloat(leafRef[1]), bitsFloat(leafRef[2]), bitsFloat(leafRef[3]));
-                rec[13] = f4(bitsFloat(leafRef[4]), bitsFloat(leafRef[5]), bitsFloat(leafRef[6]), bitsFloat(leafRef[7]));
-                rec[14] = f4(bitsFloat(childBase), bitsFloat(imask | (lmask << 8)), 0.0f, 0.0f);
-                rec[15] = f4(0.0f, 0.0f, 0.0f, 0.0f);
+                writeNode(&out.nodes[(size_t)self * kNodeFloat4s], lo, hi, leafRef, childBase, imask, lmask,
+                          q == 0 ? (uint32_t)modelIndex : kNoModel);
             }
         }
-        out.maxDepth = std::max(out.maxDepth, builder.deepest);
+        out.maxDepth = std::max(out.maxDepth, std::max(1, builder.deepest));
     }
 
     F4 mat[3];
@@ -286,6 +301,76 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
     return true;
 }
 
+namespace {
+
+struct ForestItem {
+    int model;
+    Box box;          // padded bounds of the model's reachable triangles
+    float centre[3];
+};
+
+// Fills node `self` for items[first, first + count).  A single item means `self` is that model's root, which
+// flattenModel writes later.  Otherwise the items are dealt into up to eight groups - by octant around the middle
+// of their centres while that separates them and the forest is shallow, by equal index ranges after that - and every
+// group becomes one internal child; the children of a node are contiguous.
+void buildForest(std::vector<ForestItem>& items, int first, int count, uint32_t self, int depth, FlatScene& out,
+                 std::vector<uint32_t>& rootIndex, int& deepest) {
+    if (count == 1) { rootIndex[(size_t)items[(size_t)first].model] = self; return; }
+    deepest = std::max(deepest, depth + 1);
+
+    int slotOf[8], groupFirst[8], groupCount[8];
+    int groups = 0;
+    bool spatial = false;
+    if (depth < 4) {
+        Box cb;
+        for (int i = 0; i < count; i++) cb.grow(items[(size_t)(first + i)].centre);
+        float mid[3];
+        for (int a = 0; a < 3; a++) mid[a] = 0.5f * cb.lo[a] + 0.5f * cb.hi[a];
+        auto octant = [&](const ForestItem& it) {
+            return (it.centre[0] > mid[0] ? 1 : 0) | (it.centre[1] > mid[1] ? 2 : 0) | (it.centre[2] > mid[2] ? 4 : 0);
+        };
+        int cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        for (int i = 0; i < count; i++) cnt[octant(items[(size_t)(first + i)])]++;
+        if (*std::max_element(cnt, cnt + 8) < count) {
+            spatial = true;
+            std::stable_sort(items.begin() + first, items.begin() + first + count,
+                             [&](const ForestItem& a, const ForestItem& b) { return octant(a) < octant(b); });
+            int at = first;
+            for (int c = 0; c < 8; c++) {
+                if (cnt[c] == 0) continue;
+                slotOf[groups] = c; groupFirst[groups] = at; groupCount[groups] = cnt[c];
+                at += cnt[c]; groups++;
+            }
+        }
+    }
+    if (!spatial) {
+        groups = count < 8 ? count : 8;
+        for (int g = 0; g < groups; g++) {
+            const int lo = (int)((int64_t)count * g / groups), hi = (int)((int64_t)count * (g + 1) / groups);
+            slotOf[g] = g; groupFirst[g] = first + lo; groupCount[g] = hi - lo;
+        }
+    }
+
+    const float inf = std::numeric_limits<float>::infinity();
+    float lo[3][8], hi[3][8];
+    const uint32_t leafRef[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int c = 0; c < 8; c++) for (int a = 0; a < 3; a++) { lo[a][c] = inf; hi[a][c] = -inf; }
+    uint32_t imask = 0;
+    const uint32_t childBase = (uint32_t)(out.nodes.size() / kNodeFloat4s);
+    out.nodes.resize(out.nodes.size() + (size_t)groups * kNodeFloat4s);
+    for (int g = 0; g < groups; g++) {
+        Box b;
+        for (int i = 0; i < groupCount[g]; i++) b.grow(items[(size_t)(groupFirst[g] + i)].box);
+        for (int a = 0; a < 3; a++) { lo[a][slotOf[g]] = b.lo[a]; hi[a][slotOf[g]] = b.hi[a]; }
+        imask |= 1u << slotOf[g];
+    }
+    writeNode(&out.nodes[(size_t)self * kNodeFloat4s], lo, hi, leafRef, childBase, imask, 0u, kNoModel);
+    // slots ascend with g, so the g-th group is the g-th internal child
+    for (int g = 0; g < groups; g++) buildForest(items, groupFirst[g], groupCount[g], childBase + (uint32_t)g, depth + 1, out, rootIndex, deepest);
+}
+
+}  // namespace
+
 bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err) {
     out = FlatScene();
     if (s.sphereCount < 0 || s.planeCount < 0 || s.AABBCount < 0 || s.modelCount < 0) { err = "negative object count"; return false; }
@@ -296,7 +381,7 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err) {
     OctreeParams params;
     if (s.octreeMaxDepth > 0) params.maxDepth = s.octreeMaxDepth;
     if (s.octreeLeafTriangles > 0) params.leafTriangles = s.octreeLeafTriangles;
-    if (params.maxDepth > kMaxOctreeDepth) { err = "octreeMaxDepth exceeds " + std::to_string(kMaxOctreeDepth); return false; }
+    if (params.maxDepth > kMaxModelOctreeDepth) { err = "octreeMaxDepth exceeds " + std::to_string(kMaxModelOctreeDepth); return false; }
 
     F4 mat[3];
     for (int i = 0; i < s.sphereCount; i++) {
@@ -319,9 +404,35 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err) {
         packMaterial(o.mat, o.objectType, o.debug ? 1u : 0u, mat);
         out.boxMat.insert(out.boxMat.end(), mat, mat + 3);
     }
+    // Forest over the models: reserve a root node for every model with reachable triangles and group those roots
+    // by position, so that a ray only meets the models whose (padded) triangle bounds it crosses.
+    std::vector<Box> tight((size_t)s.modelCount);
+    std::vector<float> pad((size_t)s.modelCount, 0.0f);
+    std::vector<uint32_t> rootIndex((size_t)s.modelCount, kNoRoot);
+    std::vector<ForestItem> items;
     for (int i = 0; i < s.modelCount; i++) {
-        if (!flattenModel(s.models[i], i, params, out, err)) return false;
+        if (!modelBounds(s.models[i], i, tight[(size_t)i], pad[(size_t)i], err)) return false;
+        if (reachableTriangles(s.models[i].indicesCount) == 0) continue;
+        ForestItem it;
+        it.model = i;
+        for (int a = 0; a < 3; a++) {
+            it.box.lo[a] = tight[(size_t)i].lo[a] - pad[(size_t)i];
+            it.box.hi[a] = tight[(size_t)i].hi[a] + pad[(size_t)i];
+            it.centre[a] = 0.5f * it.box.lo[a] + 0.5f * it.box.hi[a];
+        }
+        items.push_back(it);
     }
+    int forestDepth = 0;
+    if (!items.empty()) {
+        out.forestRoot = 0;
+        out.nodes.resize(kNodeFloat4s);
+        buildForest(items, 0, (int)items.size(), 0u, 0, out, rootIndex, forestDepth);
+    }
+    for (int i = 0; i < s.modelCount; i++) {
+        if (!flattenModel(s.models[i], i, params, rootIndex[(size_t)i], tight[(size_t)i], pad[(size_t)i], out, err)) return false;
+    }
+    out.maxDepth += forestDepth;
+    if (out.maxDepth >= kMaxOctreeDepth) { err = "forest plus octree nesting exceeds the traversal stack"; return false; }
     // one spare triangle record: the intersection loop requests record i + 1 while it works on record i
     if (!out.tris.empty()) { for (int k = 0; k < 3; k++) out.tris.push_back(f4(0.0f, 0.0f, 0.0f, 0.0f)); }
     out.nodeCount = (int64_t)(out.nodes.size() / kNodeFloat4s);
@@ -333,9 +444,10 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err) {
 namespace {
 
 struct Walker {
-    const rt_model& model;
+    const rt_scene_desc& scene;
     const FlatScene& flat;
-    std::vector<uint8_t> seen;
+    std::vector<std::vector<uint8_t>> seen;   // per model, per reachable triangle
+    std::vector<uint8_t> rootSeen;
     std::string err;
     int deepest = 0;
 
@@ -343,14 +455,19 @@ struct Walker {
         return p.x >= lo[0] && p.x <= hi[0] && p.y >= lo[1] && p.y <= hi[1] && p.z >= lo[2] && p.z <= hi[2];
     }
 
-    bool leaf(uint32_t start, const float lo[3], const float hi[3]) {
+    bool leaf(int m, uint32_t start, const float lo[3], const float hi[3]) {
+        const rt_model& model = scene.models[m];
+        std::vector<uint8_t>& mine = seen[(size_t)m];
         for (uint32_t t = start;; t++) {
             if ((size_t)t * 3 + 2 >= flat.tris.size()) { err = "leaf runs past the triangle array"; return false; }
-            uint32_t idw; std::memcpy(&idw, &flat.tris[(size_t)t * 3].w, 4);
+            uint32_t idw, owner;
+            std::memcpy(&idw, &flat.tris[(size_t)t * 3].w, 4);
+            std::memcpy(&owner, &flat.tris[(size_t)t * 3 + 1].w, 4);
+            if (owner != (uint32_t)m) { err = "triangle record tagged with another model"; return false; }
             uint32_t id = idw & kTriIdMask;
-            if (id >= seen.size()) { err = "triangle id out of range"; return false; }
-            if (seen[id]) { err = "triangle " + std::to_string(id) + " appears in two leaves"; return false; }
-            seen[id] = 1;
+            if (id >= mine.size()) { err = "triangle id out of range"; return false; }
+            if (mine[id]) { err = "triangle " + std::to_string(id) + " appears in two leaves"; return false; }
+            mine[id] = 1;
             const int32_t* ix = model.indices + 3 * (int64_t)id;
             const rt_vec3& p0 = model.vertices[ix[0]].position;
             const F4& v0 = flat.tris[(size_t)t * 3];
@@ -362,15 +479,25 @@ struct Walker {
         }
     }
 
-    bool node(uint32_t index, const float plo[3], const float phi[3], int depth) {
-        if (depth >= kMaxOctreeDepth) { err = "octree deeper than the traversal stack"; return false; }
+    // m: model whose octree the node belongs to, -1 above the model roots
+    bool node(uint32_t index, int m, const float plo[3], const float phi[3], int depth) {
+        if (depth >= kMaxOctreeDepth) { err = "nesting deeper than the traversal stack"; return false; }
         deepest = std::max(deepest, depth + 1);
         if ((size_t)(index + 1) * kNodeFloat4s > flat.nodes.size()) { err = "node index out of range"; return false; }
         const F4* rec = &flat.nodes[(size_t)index * kNodeFloat4s];
-        uint32_t childBase, masks;
-        std::memcpy(&childBase, &rec[14].x, 4); std::memcpy(&masks, &rec[14].y, 4);
+        uint32_t childBase, masks, owner;
+        std::memcpy(&childBase, &rec[14].x, 4); std::memcpy(&masks, &rec[14].y, 4); std::memcpy(&owner, &rec[14].z, 4);
+        if (owner != kNoModel) {
+            if (m >= 0) { err = "model root below another model's root"; return false; }
+            if (owner >= (uint32_t)scene.modelCount) { err = "model root with a model index out of range"; return false; }
+            if (rootSeen[owner]) { err = "model " + std::to_string(owner) + " has two roots"; return false; }
+            if (flat.mdlInfo[4 * (size_t)owner] != index) { err = "model table does not point at the model's root"; return false; }
+            rootSeen[owner] = 1;
+            m = (int)owner;
+        }
         const uint32_t imask = masks & 0xffu, lmask = (masks >> 8) & 0xffu;
         if (imask & lmask) { err = "slot marked both internal and leaf"; return false; }
+        if (m < 0 && lmask) { err = "leaf above the model roots"; return false; }
         uint32_t next = childBase;
         for (int c = 0; c < 8; c++) {
             float lo[3], hi[3];
@@ -388,9 +515,9 @@ struct Walker {
             }
             if ((lmask >> c) & 1u) {
                 uint32_t ref; std::memcpy(&ref, &(&rec[12 + c / 4].x)[c % 4], 4);
-                if (!leaf(ref, lo, hi)) return false;
+                if (!leaf(m, ref, lo, hi)) return false;
             } else {
-                if (!node(next++, lo, hi, depth + 1)) return false;
+                if (!node(next++, m, lo, hi, depth + 1)) return false;
             }
         }
         return true;
@@ -402,19 +529,16 @@ struct Walker {
 bool validateFlatScene(const rt_scene_desc& scene, const FlatScene& flat, std::string& err) {
     if ((int)flat.mdlInfo.size() != 4 * scene.modelCount) { err = "model table size mismatch"; return false; }
     const float inf = std::numeric_limits<float>::infinity();
+    Walker w{scene, flat, {}, std::vector<uint8_t>((size_t)scene.modelCount, 0), std::string(), 0};
+    for (int m = 0; m < scene.modelCount; m++) w.seen.emplace_back((size_t)reachableTriangles(scene.models[m].indicesCount), 0);
+    const float lo[3] = {-inf, -inf, -inf}, hi[3] = {inf, inf, inf};
+    if (flat.forestRoot != kNoRoot && !w.node(flat.forestRoot, -1, lo, hi, 0)) { err = "forest: " + w.err; return false; }
     for (int m = 0; m < scene.modelCount; m++) {
-        const rt_model& model = scene.models[m];
-        const int64_t nTri = reachableTriangles(model.indicesCount);
-        Walker w{model, flat, std::vector<uint8_t>((size_t)nTri, 0), std::string(), 0};
-        const uint32_t rootRef = flat.mdlInfo[4 * m];
-        const float lo[3] = {-inf, -inf, -inf}, hi[3] = {inf, inf, inf};
-        bool ok = true;
-        if (rootRef == kNoRoot) ok = (nTri == 0);
-        else if (rootRef & kLeafFlag) ok = w.leaf(rootRef & ~kLeafFlag, lo, hi);
-        else ok = w.node(rootRef, lo, hi, 0);
-        if (!ok) { err = "model " + std::to_string(m) + ": " + (w.err.empty() ? "empty model has a root" : w.err); return false; }
-        for (int64_t t = 0; t < nTri; t++) {
-            if (!w.seen[(size_t)t]) { err = "model " + std::to_string(m) + ": triangle " + std::to_string(t) + " is in no leaf"; return false; }
+        const bool empty = w.seen[(size_t)m].empty();
+        if (empty != (flat.mdlInfo[4 * (size_t)m] == kNoRoot)) { err = "model " + std::to_string(m) + ": root reference does not match its triangle count"; return false; }
+        if (!empty && !w.rootSeen[(size_t)m]) { err = "model " + std::to_string(m) + ": the forest never reaches its root"; return false; }
+        for (size_t t = 0; t < w.seen[(size_t)m].size(); t++) {
+            if (!w.seen[(size_t)m][t]) { err = "model " + std::to_string(m) + ": triangle " + std::to_string(t) + " is in no leaf"; return false; }
         }
     }
     return true;

@@ -23,7 +23,8 @@ struct FlatScene {
     std::vector<F4> nodes, tris, attrs;
     float lightPos[3] = {0, 0, 0}, lightCol[3] = {0, 0, 0};
     int64_t triangleCount = 0, nodeCount = 0, leafCount = 0;
-    int maxDepth = 0;
+    int maxDepth = 0;               // deepest nesting of internal nodes, forest levels included
+    uint32_t forestRoot = kNoRoot;  // node the mesh traversal starts from
 };
 
 // Number of triangles the reference's loops visit for a model with this many indices
@@ -34,7 +35,8 @@ int64_t reachableTriangles(int64_t indicesCount);
 bool flattenScene(const rt_scene_desc& scene, FlatScene& out, std::string& err);
 
 // Walks the flattened octrees of `flat` (built from `scene`) and checks the invariants the traversal kernel relies on:
-// every reachable triangle of every model sits in exactly one leaf, inside the padded box of the slot that holds it;
+// the forest reaches every non-empty model's root exactly once; every reachable triangle of every model sits in
+// exactly one leaf below that root, inside the padded box of the slot that holds it and tagged with its model;
 // child boxes nest; internal children are contiguous and in range; no path is deeper than the traversal stack.
 bool validateFlatScene(const rt_scene_desc& scene, const FlatScene& flat, std::string& err);
 

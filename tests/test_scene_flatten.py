@@ -9,14 +9,14 @@ load_package()
 from cuda_ray_tracer_amd import binding, scenes  # noqa: E402
 
 
-@pytest.mark.parametrize("leaf,depth", [(1, 12), (2, 8), (4, 8), (8, 6), (64, 2), (1000000, 1)])
+@pytest.mark.parametrize("leaf,depth", [(1, 10), (2, 8), (4, 8), (8, 6), (64, 2), (1000000, 1)])
 def test_octree_invariants_hold_for_every_shape(leaf, depth):
     spec, cfg, _, _ = scenes.config_scene(3, detail=0.3)
     built = scenes.build_scene(spec, octree_max_depth=depth, octree_leaf_triangles=leaf)
     info = binding.validate_scene_host(built.desc)
     total = sum(m.triangle_count - 1 for m in built.model_meshes)      # the last triangle of each model is unreachable
     assert info.triangleCount == total
-    assert info.maxDepth <= depth
+    assert info.maxDepth <= depth + 1                                  # one forest level above the four models
     assert info.leafCount >= 3
 
 
@@ -76,3 +76,21 @@ def test_meshgen_is_deterministic_and_outward_facing():
         assert (facing >= -1e-9).all(), name                      # counter-clockwise around the normal
         assert np.array_equal(m.indices, np.arange(len(m.indices)))
         assert sum(c for _, _, c in m.groups) == m.triangle_count
+
+
+def test_forest_over_many_models():
+    # more models than one forest node holds, some stacked on the same spot (cannot be separated by position),
+    # one empty: every non-empty root must be reached exactly once
+    tri = [[-0.3, -0.3, 0], [0.3, -0.3, 0], [0, 0.3, 0]]
+    mesh = {"t": mesh_from_triangles([tri] * 5), "e": mesh_from_triangles([tri])}
+    models = []
+    for i in range(90):
+        pos = (0, 0, -5) if i % 3 == 0 else (i % 10 - 5, i // 10 - 4, -8 - (i % 4))
+        models.append(scenes.ModelSpec("e" if i == 17 else "t", pos, 1, MATTE))
+    built = scenes.build_scene(simple_spec(models=models), meshes=mesh)
+    info = binding.validate_scene_host(built.desc)
+    assert info.modelCount == 90 and info.triangleCount == 89 * 4
+    assert 2 <= info.maxDepth <= 8
+    spec, cfg, w, h = scenes.config_scene(5, detail=0.1)
+    info = binding.validate_scene_host(scenes.build_scene(spec).desc)
+    assert info.modelCount == 144
