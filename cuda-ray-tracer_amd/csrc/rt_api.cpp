@@ -116,25 +116,37 @@ rt::FrameParams frameFor(const rt_ctx* ctx, int width, int height, int rank, int
 
 // Launches the render kernel for `p` with cost-ordered dispatch: tiles are started in the order of their measured cost
 // on the previous frame of the same geometry, and this frame's costs are ranked afterwards for the next one.
-int launchOrdered(rt_ctx* ctx, const rt::FrameParams& p, uint8_t* out, int32_t* ids, float* tbuf, unsigned long long* counters,
+// Decides how the frame is dispatched: whether tiles are cost-ordered and whether an order from the previous frame of the
+// same geometry exists.
+struct DispatchPlan { bool ordered, haveOrder; long long key; rt::FrameParams p; };
+
+DispatchPlan planDispatch(const rt_ctx* ctx, const rt::FrameParams& p) {
+    DispatchPlan d;
+    d.p = p;
+    d.ordered = ctx->costOrdering && p.blockOrder == 2 && p.ownedTiles > 0 && p.ownedTiles <= kMaxOrderedTiles;
+    d.key = ((long long)p.width << 40) ^ ((long long)p.height << 20) ^ ((long long)p.world << 8) ^ (long long)p.rank;
+    d.haveOrder = d.ordered && ctx->orderKey == d.key;
+    return d;
+}
+
+int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32_t* ids, float* tbuf, unsigned long long* counters,
                   bool instrumented, hipStream_t stream, unsigned long long* waveClocks = nullptr) {
-    const bool use = ctx->costOrdering && p.blockOrder == 2 && p.ownedTiles > 0 && p.ownedTiles <= kMaxOrderedTiles;
-    if (!use) {
+    const DispatchPlan plan = planDispatch(ctx, frame);
+    const rt::FrameParams& p = plan.p;
+    if (!plan.ordered) {
         RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks));
         return RT_OK;
     }
-    const long long key = ((long long)p.width << 40) ^ ((long long)p.height << 20) ^ ((long long)p.world << 8) ^ (long long)p.rank;
-    const bool haveOrder = ctx->orderKey == key;
     // Two cost buffers: this frame accumulates into `cur`; the ranking pass that follows reads it and clears `nxt`, which the
     // next frame accumulates into.  A change of frame geometry starts over from cleared buffers and plain tile order.
-    if (!haveOrder) RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2, stream));
+    if (!plan.haveOrder) RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2, stream));
     uint32_t* cur = ctx->dTileCost + (size_t)ctx->costSlot * kMaxOrderedTiles;
     uint32_t* nxt = ctx->dTileCost + (size_t)(ctx->costSlot ^ 1) * kMaxOrderedTiles;
     RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks,
-                            haveOrder ? ctx->dTileOrder : nullptr, cur));
+                            plan.haveOrder ? ctx->dTileOrder : nullptr, cur));
     RT_HIP(rt::launchRankTiles(cur, ctx->dTileOrder, nxt, p.ownedTiles, stream));
     ctx->costSlot ^= 1;
-    ctx->orderKey = key;
+    ctx->orderKey = plan.key;
     return RT_OK;
 }
 

@@ -9,22 +9,26 @@
 namespace rt {
 
 // ---- octree ----
-// One node is 256 bytes (two 128-byte cache lines) and describes its eight child octants:
-//   f4[0..1]  lo.x of children 0-3, 4-7      f4[6..7]   hi.x
-//   f4[2..3]  lo.y                           f4[8..9]   hi.y
-//   f4[4..5]  lo.z                           f4[10..11] hi.z
-//   u4[12..13] leafRef[8]: first triangle of a leaf child in the leaf-ordered triangle array
-//   u4[14]    { childBase, internalMask | leafMask << 8, model, 0 }
-//   u4[15]    unused
+// One node is 128 bytes (one cache line) and describes its eight child octants with boxes quantised to 8 bits per
+// plane against a per-node origin and per-axis power-of-two step:
+//   u4[0]  { bits(origin.x), bits(origin.y), bits(origin.z), ex | ey << 8 | ez << 16 }   step_a = 2^(e_a - 127)
+//   u4[1]  { childBase, internalMask | leafMask << 8, model, 0 }
+//   u4[2]  x planes: qlo of children 0-3, qlo of 4-7, qhi of 0-3, qhi of 4-7 (one byte per child, child c in byte c % 4)
+//   u4[3]  y planes, u4[4] z planes, same order
+//   u4[5..6] leafRef[8]: first triangle of a leaf child in the leaf-ordered triangle array
+//   u4[7]  unused
+// Child c spans [origin + qlo * step, origin + qhi * step] on each axis; the host rounds qlo down and qhi up, so the
+// decoded box always encloses the (already padded) box it was made from.  Empty slots hold qlo = 255, qhi = 0 and are
+// masked out by internalMask / leafMask.
 // Internal children are stored contiguously from childBase in slot order, so child slot c is node
-// childBase + popcount(internalMask & ((1 << c) - 1)).  Empty slots hold an inverted box (lo = +inf, hi = -inf).
+// childBase + popcount(internalMask & ((1 << c) - 1)).
 // Slot c is the octant (x > cx) | (y > cy) << 1 | (z > cz) << 2 of the node's split point.
 //
 // All models hang off one forest: nodes above the models group model roots by position, and the root node of a model's
 // own octree carries the model's index in `model` (kNoModel everywhere else).  The traversal evaluates the model's
 // exact bounding-box gate when it reaches such a node.  A scene with a single non-empty model has that model's root as
 // the forest root.
-constexpr int kNodeFloat4s = 16;
+constexpr int kNodeFloat4s = 8;
 constexpr uint32_t kNoRoot = 0xFFFFFFFFu;     // model without triangles / scene without mesh triangles
 constexpr uint32_t kNoModel = 0xFFFFFFFFu;
 constexpr int kMaxOctreeDepth = 16;           // nesting levels (forest + model octree) the traversal stack can hold

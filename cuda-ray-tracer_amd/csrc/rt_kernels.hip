@@ -50,6 +50,7 @@ RT_DEV float selMin(float x, float y) { return (x < y) ? x : y; }   // utils.h:8
 
 RT_DEV f4_t ld4(const F4* p) { return *reinterpret_cast<const f4_t*>(p); }
 RT_DEV uint32_t fbits(float f) { return __float_as_uint(f); }
+RT_DEV float ubits(uint32_t u) { return __uint_as_float(u); }
 
 // float -> int, toward zero, saturating, NaN -> 0 (v_cvt_i32_f32 semantics, spelled out).
 RT_DEV int f2iRz(float f) {
@@ -202,12 +203,10 @@ RT_DEV uint32_t permuteOctants(uint32_t m, uint32_t oct) {
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
-// Per-ray constants of the approximate slab tests: rd = 1/d (v_rcp_f32, 1 ulp), ord = o * rd, and for each axis which
-// of a node's two float4 pairs holds the plane the ray enters through (lo if the direction is positive, hi otherwise).
+// Per-ray constants of the approximate slab tests: rd = 1/d (v_rcp_f32, 1 ulp), ord = o * rd.
 struct SlabRay {
     V3 rd, ord;
     uint32_t oct;            // bit a set: the ray travels towards -a (sign bit of d, so that -0 pairs with rd = -inf)
-    int nearX, nearY, nearZ; // float4 index of the entry planes inside a node record; the exit planes are 6 further / nearer
 };
 
 RT_DEV SlabRay makeSlabRay(V3 o, V3 d) {
@@ -215,27 +214,29 @@ RT_DEV SlabRay makeSlabRay(V3 o, V3 d) {
     r.rd = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
     r.ord = mk(o.x * r.rd.x, o.y * r.rd.y, o.z * r.rd.z);
     r.oct = (fbits(d.x) >> 31) | ((fbits(d.y) >> 31) << 1) | ((fbits(d.z) >> 31) << 2);
-    r.nearX = (r.oct & 1u) ? 6 : 0;
-    r.nearY = (r.oct & 2u) ? 8 : 2;
-    r.nearZ = (r.oct & 4u) ? 10 : 4;
     return r;
 }
 
-// Four children at once: entry/exit parameters along each axis, then interval overlap with [0, tmax].
-// fmaxf/fminf drop a NaN operand (inf - inf on an axis-parallel ray), which keeps the test conservative.
-RT_DEV uint32_t testFour(f4_t nx, f4_t ny, f4_t nz, f4_t fx, f4_t fy, f4_t fz, const SlabRay& r, float tmin, float tmax) {
-    const f2_t rx = {r.rd.x, r.rd.x}, ry = {r.rd.y, r.rd.y}, rz = {r.rd.z, r.rd.z};
-    const f2_t ox = {-r.ord.x, -r.ord.x}, oy = {-r.ord.y, -r.ord.y}, oz = {-r.ord.z, -r.ord.z};
+RT_DEV float byteToFloat(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyte<k>
+
+// Four children at once.  n* / f* hold the quantised entry / exit planes of the four children on each axis (one byte
+// each); a plane at byte value q lies at ray parameter q * s + b.  Then interval overlap with [tmin, tmax].
+// fmaxf/fminf drop a NaN operand (0 * inf or inf - inf on an axis-parallel ray), which keeps the test conservative.
+RT_DEV uint32_t testFour(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uint32_t fy, uint32_t fz, V3 s, V3 b, float tmin, float tmax) {
+    const f2_t sx = {s.x, s.x}, sy = {s.y, s.y}, sz = {s.z, s.z};
+    const f2_t bx = {b.x, b.x}, by = {b.y, b.y}, bz = {b.z, b.z};
     uint32_t mask = 0;
 #pragma unroll
     for (int h = 0; h < 2; h++) {
-        f2_t a = h ? f2_t{nx.z, nx.w} : f2_t{nx.x, nx.y}, b = h ? f2_t{ny.z, ny.w} : f2_t{ny.x, ny.y}, c = h ? f2_t{nz.z, nz.w} : f2_t{nz.x, nz.y};
-        f2_t e = h ? f2_t{fx.z, fx.w} : f2_t{fx.x, fx.y}, f = h ? f2_t{fy.z, fy.w} : f2_t{fy.x, fy.y}, g = h ? f2_t{fz.z, fz.w} : f2_t{fz.x, fz.y};
-        a = __builtin_elementwise_fma(a, rx, ox); b = __builtin_elementwise_fma(b, ry, oy); c = __builtin_elementwise_fma(c, rz, oz);
-        e = __builtin_elementwise_fma(e, rx, ox); f = __builtin_elementwise_fma(f, ry, oy); g = __builtin_elementwise_fma(g, rz, oz);
+        f2_t a = {byteToFloat(nx, 2 * h), byteToFloat(nx, 2 * h + 1)}, bb = {byteToFloat(ny, 2 * h), byteToFloat(ny, 2 * h + 1)};
+        f2_t c = {byteToFloat(nz, 2 * h), byteToFloat(nz, 2 * h + 1)};
+        f2_t e = {byteToFloat(fx, 2 * h), byteToFloat(fx, 2 * h + 1)}, f = {byteToFloat(fy, 2 * h), byteToFloat(fy, 2 * h + 1)};
+        f2_t g = {byteToFloat(fz, 2 * h), byteToFloat(fz, 2 * h + 1)};
+        a = __builtin_elementwise_fma(a, sx, bx); bb = __builtin_elementwise_fma(bb, sy, by); c = __builtin_elementwise_fma(c, sz, bz);
+        e = __builtin_elementwise_fma(e, sx, bx); f = __builtin_elementwise_fma(f, sy, by); g = __builtin_elementwise_fma(g, sz, bz);
 #pragma unroll
         for (int k = 0; k < 2; k++) {
-            float tn = fmaxf(fmaxf(a[k], b[k]), fmaxf(c[k], tmin));
+            float tn = fmaxf(fmaxf(a[k], bb[k]), fmaxf(c[k], tmin));
             float tf = fminf(fminf(e[k], f[k]), fminf(g[k], tmax));
             mask |= (tn <= tf) ? (1u << (2 * h + k)) : 0u;
         }
@@ -243,15 +244,20 @@ RT_DEV uint32_t testFour(f4_t nx, f4_t ny, f4_t nz, f4_t fx, f4_t fy, f4_t fz, c
     return mask;
 }
 
-// Conservative slab test of the eight child boxes of one node; returns the bit mask of children whose box overlaps
-// [tmin, tmax] along the ray (tmin is 0, or -inf for the mesh mode without a t > 0 test).  Conservative because the host pads every child box by more than the worst-case error of
-// the fma / reciprocal form for coordinates and ray origins up to a few thousand units (rt_scene.cpp).
-RT_DEV uint32_t testChildren(const F4* node, const SlabRay& r, float tmin, float tmax) {
-    const F4* nX = node + r.nearX; const F4* fX = node + (6 - r.nearX);
-    const F4* nY = node + r.nearY; const F4* fY = node + (10 - r.nearY);
-    const F4* nZ = node + r.nearZ; const F4* fZ = node + (14 - r.nearZ);
-    uint32_t lo4 = testFour(ld4(nX), ld4(nY), ld4(nZ), ld4(fX), ld4(fY), ld4(fZ), r, tmin, tmax);
-    uint32_t hi4 = testFour(ld4(nX + 1), ld4(nY + 1), ld4(nZ + 1), ld4(fX + 1), ld4(fY + 1), ld4(fZ + 1), r, tmin, tmax);
+// Conservative slab test of the eight child boxes of one node (head = the node's first 16 bytes); returns the bit mask
+// of slots whose decoded box overlaps [tmin, tmax] along the ray (tmin is 0, or -inf for the mesh mode without a t > 0
+// test).  Bits of unused slots are meaningless.  Conservative because the host pads every child box by more than the
+// worst-case error of the fma / reciprocal form for coordinates and ray origins up to a few thousand units
+// (rt_scene.cpp) before rounding it outwards onto the node's grid.
+RT_DEV uint32_t testChildren(const F4* node, u4_t head, const SlabRay& r, float tmin, float tmax) {
+    const u4_t qx = *reinterpret_cast<const u4_t*>(node + 2), qy = *reinterpret_cast<const u4_t*>(node + 3), qz = *reinterpret_cast<const u4_t*>(node + 4);
+    // plane at origin + q * step  ->  parameter (origin + q * step - o) / d = q * (step * rd) + (origin * rd - o * rd)
+    const V3 s = mk(ubits((head.w & 0xffu) << 23) * r.rd.x, ubits(((head.w >> 8) & 0xffu) << 23) * r.rd.y, ubits(((head.w >> 16) & 0xffu) << 23) * r.rd.z);
+    const V3 b = mk(__builtin_fmaf(ubits(head.x), r.rd.x, -r.ord.x), __builtin_fmaf(ubits(head.y), r.rd.y, -r.ord.y), __builtin_fmaf(ubits(head.z), r.rd.z, -r.ord.z));
+    // the ray enters through the low planes on axes it travels along in the positive direction, the high planes otherwise
+    const bool px = !(r.oct & 1u), py = !(r.oct & 2u), pz = !(r.oct & 4u);
+    uint32_t lo4 = testFour(px ? qx.x : qx.z, py ? qy.x : qy.z, pz ? qz.x : qz.z, px ? qx.z : qx.x, py ? qy.z : qy.x, pz ? qz.z : qz.x, s, b, tmin, tmax);
+    uint32_t hi4 = testFour(px ? qx.y : qx.w, py ? qy.y : qy.w, pz ? qz.y : qz.w, px ? qx.w : qx.y, py ? qy.w : qy.y, pz ? qz.w : qz.y, s, b, tmin, tmax);
     return lo4 | (hi4 << 4);
 }
 
@@ -274,6 +280,7 @@ RT_DEV bool tightBoxHit(V3 lo, V3 hi, const SlabRay& r, float tmin, float tmax) 
 template <bool ANYHIT, bool STATS>
 RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, Closest& best, StackRef stk, Counters& cnt) {
     if (S.forestRoot == kNoRoot) return false;
+    SectionTimer<STATS> timerWhole;
     const int nMdl = S.nMdl;
     const bool positiveOnly = meshMode != kMeshNoBox;
     const float tmin = positiveOnly ? 0.0f : -__builtin_inff();
@@ -306,7 +313,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
             if (gate(j)) gateBits |= 1ull << j;
         }
         timerG.stop(stk, 2);
-        if (gateBits == 0) return false;
+        if (gateBits == 0) { timerWhole.stop(stk, 3); return false; }
     }
 
     // children still to visit below the current node; the start state is one pseudo child that resolves to the forest root
@@ -333,22 +340,26 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
             uint32_t c = k ^ oct;
             const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
 
+            // The whole 128-byte record is requested at once and nothing below branches before the box test, so a node
+            // visit costs one memory round trip (leaf references included, whether or not a leaf is hit).
             const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
-            u4_t meta = *reinterpret_cast<const u4_t*>(np + 14);
-            if (meta.z != kNoModel) {       // root of a model's octree
+            const u4_t head = *reinterpret_cast<const u4_t*>(np), meta = *reinterpret_cast<const u4_t*>(np + 1);
+            const u4_t ra = *reinterpret_cast<const u4_t*>(np + 5), rb = *reinterpret_cast<const u4_t*>(np + 6);
+            uint32_t hmask = testChildren(np, head, sr, tmin, ANYHIT ? FAR_T : best.t);
+            if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
                 const int mm = (int)meta.z;
-                if (pregated ? !((gateBits >> mm) & 1ull) : !gate(mm)) continue;
-                if (meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
+                bool enter = pregated ? (((gateBits >> mm) & 1ull) != 0) : gate(mm);
+                if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
                     chunkMask = 0;
                     for (int b = 0; b < 8; b++) {
                         if (STATS) cnt.gateTests++;
                         float tGate;
                         if (boxHit(xyz(ld4(S.mdlChunkMin + 8 * mm + b)), xyz(ld4(S.mdlChunkMax + 8 * mm + b)), o, d, tGate)) chunkMask |= 1u << b;
                     }
-                    if (chunkMask == 0) continue;
+                    enter = chunkMask != 0;
                 }
+                if (!enter) hmask = 0;
             }
-            uint32_t hmask = testChildren(np, sr, tmin, ANYHIT ? FAR_T : best.t);
             uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
             if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
             if (hits != 0) {   // keep the siblings that are still waiting
@@ -359,12 +370,8 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
             base = meta.x;
             imask = nodeImask;
             hits = permuteOctants(hmask & nodeImask, oct);
-            uint32_t lhit = hmask & nodeLmask;
-            if (lhit) {
-                u4_t ra = *reinterpret_cast<const u4_t*>(np + 12), rb = *reinterpret_cast<const u4_t*>(np + 13);
-                lr0 = ra.x; lr1 = ra.y; lr2 = ra.z; lr3 = ra.w; lr4 = rb.x; lr5 = rb.y; lr6 = rb.z; lr7 = rb.w;
-                pend = permuteOctants(lhit, oct);
-            }
+            pend = permuteOctants(hmask & nodeLmask, oct);
+            lr0 = ra.x; lr1 = ra.y; lr2 = ra.z; lr3 = ra.w; lr4 = rb.x; lr5 = rb.y; lr6 = rb.z; lr7 = rb.w;
             timerA.stop(stk, 0);
         }
         if (pend == 0) break;   // nothing left
@@ -423,6 +430,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
         }
         if (ANYHIT && found) break;
     }
+    timerWhole.stop(stk, 3);
     return ANYHIT ? found : false;
 }
 
@@ -563,15 +571,6 @@ RT_DEV int renormCount(int kind, bool planesRun, bool boxesRun, bool modelsRun) 
 }
 
 // Hard-shadow test of the primary level: spheres, boxes, models (kernels.cu:268-277); one ray.
-template <bool STATS>
-RT_DEV bool fullShadow(const DevScene& S, const FrameParams& P, V3 so, V3 sd, StackRef stk, Counters& cnt) {
-    if (shadowSpheres(S, so, sd)) return true;
-    if (shadowBoxes(S, so, sd)) return true;
-    if (!(P.flags & kCfgModelsVisible)) return false;
-    Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
-    return traceModels<true, STATS>(S, so, sd, (P.flags & kCfgCull) != 0, true, P.meshMode, dummy, stk, cnt);
-}
-
 // One camera sample: kernels.cu:224-318 with the reflection chain kernels.cu:130-222 unrolled into levels.
 template <bool STATS>
 RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px, int py, StackRef stk, Counters& cnt, Closest& primaryOut) {
@@ -624,27 +623,41 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px
                     else if (h.kind == KIND_BOX && level == 0) { strength = P.boxStrength; add = true; }   // kernels.cu:259
                 }
                 bool shadowed = false;
-                if (hardShadows) {
-                    cnt.rays++;
-                    if (level == 0) shadowed = fullShadow<STATS>(S, P, biased, toLight, stk, cnt);
-                    else shadowed = shadowSpheres(S, biased, toLight);                             // kernels.cu:142, 164, 214
-                }
-                if (level == 0 && (P.flags & kCfgSoftShadows)) {                                   // kernels.cu:279-307
+                if (level == 0) {
+                    // Shadow rays of the primary hit, one loop so that the any-hit mesh traversal is instantiated once:
+                    // the hard shadow ray towards the light (kernels.cu:268-277, stops at the first occluder kind), then
+                    // the soft shadow samples (kernels.cu:279-307, every occluder kind counts separately).
+                    const int hardRays = hardShadows ? 1 : 0;
+                    const bool soft = (P.flags & kCfgSoftShadows) != 0;
+                    const int shadowRays = hardRays + (soft ? P.softNum : 0);
                     int hitsCount = 0;
-                    for (int i = 0; i < P.softNum; i++) {
-                        V3 ps = lightSampleOffset(sampleSeed(px, py, i), P.softRadius);
-                        V3 lightPoint = lightPos + ps;
-                        V3 sd = normalise(lightPoint - s.point);
-                        cnt.rays++;
-                        hitsCount += shadowSpheres(S, biased, sd) ? 1 : 0;
-                        hitsCount += shadowBoxes(S, biased, sd) ? 1 : 0;
-                        if (P.flags & kCfgModelsVisible) {   // the shadow traces ignore renderModels (kernels.cu:304)
-                            Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
-                            hitsCount += traceModels<true, STATS>(S, biased, sd, cull, true, P.meshMode, dummy, stk, cnt) ? 1 : 0;
+#pragma unroll 1
+                    for (int q = 0; q < shadowRays; q++) {
+                        const bool hard = q < hardRays;
+                        V3 sd = toLight;
+                        if (!hard) {
+                            V3 ps = lightSampleOffset(sampleSeed(px, py, q - hardRays), P.softRadius);
+                            V3 lightPoint = lightPos + ps;
+                            sd = normalise(lightPoint - s.point);
                         }
+                        cnt.rays++;
+                        const bool bySphere = shadowSpheres(S, biased, sd);
+                        const bool byBox = (hard && bySphere) ? false : shadowBoxes(S, biased, sd);
+                        bool byModel = false;
+                        if ((P.flags & kCfgModelsVisible) && !(hard && (bySphere || byBox))) {   // the shadow traces ignore renderModels (kernels.cu:304)
+                            Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
+                            byModel = traceModels<true, STATS>(S, biased, sd, cull, true, P.meshMode, dummy, stk, cnt);
+                        }
+                        if (hard) shadowed = bySphere || byBox || byModel;
+                        else hitsCount += (bySphere ? 1 : 0) + (byBox ? 1 : 0) + (byModel ? 1 : 0);
                     }
-                    softFactor = 1 - ((float)hitsCount / (float)P.softNum);
-                    useSoft = true;
+                    if (soft) {
+                        softFactor = 1 - ((float)hitsCount / (float)P.softNum);
+                        useSoft = true;
+                    }
+                } else if (hardShadows) {
+                    cnt.rays++;
+                    shadowed = shadowSpheres(S, biased, toLight);                                  // kernels.cu:142, 164, 214
                 }
                 if (level == 0) { str0 = strength; add0 = add; sh0 = shadowed; }
                 else if (level == 1) { str1 = strength; add1 = add; sh1 = shadowed; }
@@ -700,7 +713,7 @@ constexpr int kWavesPerTile = kWavesPerTileSide * kWavesPerTileSide;
 RT_DEV uint32_t evenBits3(uint32_t v) { return (v & 1u) | ((v >> 1) & 2u) | ((v >> 2) & 4u); }
 
 template <bool STATS>
-__global__ __launch_bounds__(kBlockThreads) void renderKernel(DevScene S, FrameParams P, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3))) void renderKernel(DevScene S, FrameParams P, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
                                                     float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
                                                     unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
                                                     uint32_t* __restrict__ tileCost) {
@@ -743,22 +756,22 @@ __global__ __launch_bounds__(kBlockThreads) void renderKernel(DevScene S, FrameP
         const V3 camPos = mk(P.camPos);
         V3 col;
         Closest primary; primary.t = FAR_T; primary.kind = KIND_NONE; primary.idx = -1; primary.tri = -1; primary.u = 0; primary.v = 0;
-        if (P.flags & kCfgAntiAlias) {                                      // kernels.cu:331-341
-            V3 total = mk(0, 0, 0);
-            bool first = true;
-            for (float i = 0.25f; i <= 0.75f; i += 0.5f) {
-                for (float j = 0.25f; j <= 0.75f; j += 0.5f) {
-                    V3 p = rasterToCameraSpace(P, (float)x + i, (float)y + j);
-                    Closest ph;
-                    total = total + castSample<STATS>(S, P, camPos, normalise(p), x, y, stk, cnt, ph);
-                    if (first) { primary = ph; first = false; }
-                }
-            }
-            col = total / 4.0f;
-        } else {                                                            // kernels.cu:353-357
-            V3 p = rasterToCameraSpace(P, (float)((double)x + 0.5), (float)((double)y + 0.5));
-            col = castSample<STATS>(S, P, camPos, normalise(p), x, y, stk, cnt, primary);
+        // One loop over the camera samples so that the whole ray pipeline is instantiated once: the centre of the pixel
+        // (kernels.cu:353-357), or with anti-aliasing the four points (0.25 | 0.75, 0.25 | 0.75), x offset outermost
+        // (kernels.cu:331-341).  x + 0.5 is exact in float for any frame width, like the reference's double sum.
+        const bool antiAlias = (P.flags & kCfgAntiAlias) != 0;
+        const int samples = antiAlias ? 4 : 1;
+        V3 total = mk(0, 0, 0);
+#pragma unroll 1
+        for (int sIdx = 0; sIdx < samples; sIdx++) {
+            const float offX = antiAlias ? ((sIdx & 2) ? 0.75f : 0.25f) : 0.5f, offY = antiAlias ? ((sIdx & 1) ? 0.75f : 0.25f) : 0.5f;
+            V3 p = rasterToCameraSpace(P, (float)x + offX, (float)y + offY);
+            Closest ph;
+            V3 c = castSample<STATS>(S, P, camPos, normalise(p), x, y, stk, cnt, ph);
+            if (sIdx == 0) primary = ph;
+            total = antiAlias ? total + c : c;
         }
+        col = antiAlias ? total / 4.0f : total;
         size_t pix;
         if (P.compactOutput) pix = (size_t)localTile * (RT_TILE_PX * RT_TILE_PX) + (size_t)ly * RT_TILE_PX + lx;
         else pix = (size_t)y * (size_t)P.width + (size_t)x;

@@ -123,19 +123,45 @@ void packMaterial(const rt_material& m, int objectType, uint32_t flags, F4 out[3
 
 static bool isIgnoredPosition(const rt_vec3& p) { return p.x == -999.0f && p.y == -999.0f && p.z == -999.0f; }
 
-// Writes one 256-byte node record.
+// Writes one node record: the eight child boxes lo/hi[axis][slot] (already padded; ignored for slots in neither mask)
+// are quantised outwards against the node's own origin and power-of-two steps.
 static void writeNode(F4* rec, const float lo[3][8], const float hi[3][8], const uint32_t leafRef[8], uint32_t childBase,
                       uint32_t imask, uint32_t lmask, uint32_t model) {
+    const uint32_t used = imask | lmask;
+    float origin[3] = {0.0f, 0.0f, 0.0f};
+    uint32_t expo[3] = {127u, 127u, 127u};
+    uint32_t planes[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
     for (int a = 0; a < 3; a++) {
-        rec[2 * a + 0] = f4(lo[a][0], lo[a][1], lo[a][2], lo[a][3]);
-        rec[2 * a + 1] = f4(lo[a][4], lo[a][5], lo[a][6], lo[a][7]);
-        rec[6 + 2 * a + 0] = f4(hi[a][0], hi[a][1], hi[a][2], hi[a][3]);
-        rec[6 + 2 * a + 1] = f4(hi[a][4], hi[a][5], hi[a][6], hi[a][7]);
+        double mn = std::numeric_limits<double>::infinity(), mx = -mn;
+        for (int c = 0; c < 8; c++) {
+            if (!((used >> c) & 1u)) continue;
+            mn = std::min(mn, (double)lo[a][c]); mx = std::max(mx, (double)hi[a][c]);
+        }
+        double step = 1.0;
+        if (used) {
+            origin[a] = (float)mn;
+            int ex = -126;
+            if (mx > mn) { std::frexp((mx - mn) / 255.0, &ex); }     // 2^ex >= extent / 255
+            ex = std::min(127, std::max(-126, ex));
+            expo[a] = (uint32_t)(ex + 127);
+            step = std::ldexp(1.0, ex);
+        }
+        for (int c = 0; c < 8; c++) {
+            uint32_t ql = 255u, qh = 0u;
+            if ((used >> c) & 1u) {
+                ql = (uint32_t)std::min(255.0, std::max(0.0, std::floor(((double)lo[a][c] - (double)origin[a]) / step)));
+                qh = (uint32_t)std::min(255.0, std::max(0.0, std::ceil(((double)hi[a][c] - (double)origin[a]) / step)));
+            }
+            planes[a][c / 4] |= ql << (8 * (c % 4));
+            planes[a][2 + c / 4] |= qh << (8 * (c % 4));
+        }
     }
-    rec[12] = f4(bitsFloat(leafRef[0]), bitsFloat(leafRef[1]), bitsFloat(leafRef[2]), bitsFloat(leafRef[3]));
-    rec[13] = f4(bitsFloat(leafRef[4]), bitsFloat(leafRef[5]), bitsFloat(leafRef[6]), bitsFloat(leafRef[7]));
-    rec[14] = f4(bitsFloat(childBase), bitsFloat(imask | (lmask << 8)), bitsFloat(model), 0.0f);
-    rec[15] = f4(0.0f, 0.0f, 0.0f, 0.0f);
+    rec[0] = f4(origin[0], origin[1], origin[2], bitsFloat(expo[0] | (expo[1] << 8) | (expo[2] << 16)));
+    rec[1] = f4(bitsFloat(childBase), bitsFloat(imask | (lmask << 8)), bitsFloat(model), 0.0f);
+    for (int a = 0; a < 3; a++) rec[2 + a] = f4(bitsFloat(planes[a][0]), bitsFloat(planes[a][1]), bitsFloat(planes[a][2]), bitsFloat(planes[a][3]));
+    rec[5] = f4(bitsFloat(leafRef[0]), bitsFloat(leafRef[1]), bitsFloat(leafRef[2]), bitsFloat(leafRef[3]));
+    rec[6] = f4(bitsFloat(leafRef[4]), bitsFloat(leafRef[5]), bitsFloat(leafRef[6]), bitsFloat(leafRef[7]));
+    rec[7] = f4(0.0f, 0.0f, 0.0f, 0.0f);
 }
 
 // Validates a model's arrays and returns the bounds of its reachable triangles and the padding of its child boxes.
@@ -451,11 +477,11 @@ struct Walker {
     std::string err;
     int deepest = 0;
 
-    bool inside(const float lo[3], const float hi[3], const rt_vec3& p) const {
+    bool inside(const double lo[3], const double hi[3], const rt_vec3& p) const {
         return p.x >= lo[0] && p.x <= hi[0] && p.y >= lo[1] && p.y <= hi[1] && p.z >= lo[2] && p.z <= hi[2];
     }
 
-    bool leaf(int m, uint32_t start, const float lo[3], const float hi[3]) {
+    bool leaf(int m, uint32_t start, const double lo[3], const double hi[3]) {
         const rt_model& model = scene.models[m];
         std::vector<uint8_t>& mine = seen[(size_t)m];
         for (uint32_t t = start;; t++) {
@@ -480,13 +506,14 @@ struct Walker {
     }
 
     // m: model whose octree the node belongs to, -1 above the model roots
-    bool node(uint32_t index, int m, const float plo[3], const float phi[3], int depth) {
+    bool node(uint32_t index, int m, const double plo[3], const double phi[3], int depth) {
         if (depth >= kMaxOctreeDepth) { err = "nesting deeper than the traversal stack"; return false; }
         deepest = std::max(deepest, depth + 1);
         if ((size_t)(index + 1) * kNodeFloat4s > flat.nodes.size()) { err = "node index out of range"; return false; }
         const F4* rec = &flat.nodes[(size_t)index * kNodeFloat4s];
-        uint32_t childBase, masks, owner;
-        std::memcpy(&childBase, &rec[14].x, 4); std::memcpy(&masks, &rec[14].y, 4); std::memcpy(&owner, &rec[14].z, 4);
+        uint32_t childBase, masks, owner, expo;
+        std::memcpy(&childBase, &rec[1].x, 4); std::memcpy(&masks, &rec[1].y, 4); std::memcpy(&owner, &rec[1].z, 4);
+        std::memcpy(&expo, &rec[0].w, 4);
         if (owner != kNoModel) {
             if (m >= 0) { err = "model root below another model's root"; return false; }
             if (owner >= (uint32_t)scene.modelCount) { err = "model root with a model index out of range"; return false; }
@@ -498,23 +525,26 @@ struct Walker {
         const uint32_t imask = masks & 0xffu, lmask = (masks >> 8) & 0xffu;
         if (imask & lmask) { err = "slot marked both internal and leaf"; return false; }
         if (m < 0 && lmask) { err = "leaf above the model roots"; return false; }
+        const float origin[3] = {rec[0].x, rec[0].y, rec[0].z};
         uint32_t next = childBase;
         for (int c = 0; c < 8; c++) {
-            float lo[3], hi[3];
+            if (!(((imask | lmask) >> c) & 1u)) continue;
+            // the slot's box as the traversal decodes it, clipped by the boxes of the slots above: a ray reaches this
+            // slot only through all of them, so everything stored below must lie inside their intersection
+            double lo[3], hi[3];
             for (int a = 0; a < 3; a++) {
-                const float* l = &rec[2 * a + c / 4].x; const float* h = &rec[6 + 2 * a + c / 4].x;
-                lo[a] = l[c % 4]; hi[a] = h[c % 4];
-            }
-            const bool used = ((imask | lmask) >> c) & 1u;
-            if (!used) {
-                if (!(lo[0] > hi[0])) { err = "empty slot without an inverted box"; return false; }
-                continue;
-            }
-            for (int a = 0; a < 3; a++) {
-                if (lo[a] < plo[a] - 2e-3f - 1e-5f * std::fabs(plo[a]) || hi[a] > phi[a] + 2e-3f + 1e-5f * std::fabs(phi[a])) { err = "child box outside its parent"; return false; }
+                const int e = (int)((expo >> (8 * a)) & 0xffu);
+                if (e < 1 || e > 254) { err = "quantisation step out of range"; return false; }
+                uint32_t wl, wh;
+                std::memcpy(&wl, &(&rec[2 + a].x)[c / 4], 4); std::memcpy(&wh, &(&rec[2 + a].x)[2 + c / 4], 4);
+                const double step = std::ldexp(1.0, e - 127);
+                const double l = (double)origin[a] + (double)((wl >> (8 * (c % 4))) & 0xffu) * step;
+                const double h = (double)origin[a] + (double)((wh >> (8 * (c % 4))) & 0xffu) * step;
+                lo[a] = std::max(plo[a], l);
+                hi[a] = std::min(phi[a], h);
             }
             if ((lmask >> c) & 1u) {
-                uint32_t ref; std::memcpy(&ref, &(&rec[12 + c / 4].x)[c % 4], 4);
+                uint32_t ref; std::memcpy(&ref, &(&rec[5 + c / 4].x)[c % 4], 4);
                 if (!leaf(m, ref, lo, hi)) return false;
             } else {
                 if (!node(next++, m, lo, hi, depth + 1)) return false;
@@ -528,10 +558,10 @@ struct Walker {
 
 bool validateFlatScene(const rt_scene_desc& scene, const FlatScene& flat, std::string& err) {
     if ((int)flat.mdlInfo.size() != 4 * scene.modelCount) { err = "model table size mismatch"; return false; }
-    const float inf = std::numeric_limits<float>::infinity();
+    const double inf = std::numeric_limits<double>::infinity();
     Walker w{scene, flat, {}, std::vector<uint8_t>((size_t)scene.modelCount, 0), std::string(), 0};
     for (int m = 0; m < scene.modelCount; m++) w.seen.emplace_back((size_t)reachableTriangles(scene.models[m].indicesCount), 0);
-    const float lo[3] = {-inf, -inf, -inf}, hi[3] = {inf, inf, inf};
+    const double lo[3] = {-inf, -inf, -inf}, hi[3] = {inf, inf, inf};
     if (flat.forestRoot != kNoRoot && !w.node(flat.forestRoot, -1, lo, hi, 0)) { err = "forest: " + w.err; return false; }
     for (int m = 0; m < scene.modelCount; m++) {
         const bool empty = w.seen[(size_t)m].empty();

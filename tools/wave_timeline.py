@@ -35,7 +35,7 @@ for i in range(bins):
     print(f"  {a / 100:8.1f}-{b / 100:8.1f} us: {active:7.1f} waves resident on average")
 sec = clk[valid, 2:].astype(np.float64)
 tot_cycles = dur * 2400.0   # rough: 2.4 GHz
-print("share of wave time (all waves): node visits %.1f%%, triangle tests %.1f%%, model gates %.1f%%, pops %.1f%%" % tuple(100 * sec[:, k].sum() / tot_cycles.sum() for k in (0, 2, 4, 6)))
+print("share of wave time (all waves): node visits %.1f%%, triangle tests %.1f%%, model gates %.1f%%, whole mesh traces %.1f%%" % tuple(100 * sec[:, k].sum() / tot_cycles.sum() for k in (0, 2, 4, 6)))
 heavy = dur > np.percentile(dur, 99)
 print("heavy 1%% waves: node visits %.1f%% (%.0f iters/wave, %.0f cyc/iter), triangle tests %.1f%% (%.0f iters, %.0f cyc/iter), gates %.1f%% (%.0f iters, %.0f cyc/iter)" % (
     100 * sec[heavy, 0].sum() / tot_cycles[heavy].sum(), sec[heavy, 1].mean(), sec[heavy, 0].sum() / max(sec[heavy, 1].sum(), 1),
@@ -43,4 +43,6 @@ print("heavy 1%% waves: node visits %.1f%% (%.0f iters/wave, %.0f cyc/iter), tri
     100 * sec[heavy, 4].sum() / tot_cycles[heavy].sum(), sec[heavy, 5].mean(), sec[heavy, 4].sum() / max(sec[heavy, 5].sum(), 1)))
 order = np.argsort(-dur)[:10]
 idx = np.nonzero(valid)[0][order]
+print("heavy 1%% waves: whole mesh traces %.1f%% of their time (%.0f calls/wave, %.0f cyc/call)" % (
+    100 * sec[heavy, 6].sum() / tot_cycles[heavy].sum(), sec[heavy, 7].mean(), sec[heavy, 6].sum() / max(sec[heavy, 7].sum(), 1)))
 print("slowest waves (wave index, start us, dur us):", [(int(i), round(float((clk[i, 0] - t0) / 100.0), 1), round(float((clk[i, 1] - clk[i, 0]) / 100.0), 1)) for i in idx])
