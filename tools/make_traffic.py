@@ -11,5 +11,9 @@ out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "config3", "size": [int
        "hbm_bytes_per_launch": (2.0 * summary["FETCH_SIZE"] + summary["WRITE_SIZE"]) * 1024.0,
        "l2_hit_rate": summary["TCC_HIT_sum"] / max(summary["TCC_HIT_sum"] + summary["TCC_MISS_sum"], 1.0),
        "valu_lane_utilisation": summary["SQ_THREAD_CYCLES_VALU"] / max(summary["SQ_ACTIVE_INST_VALU"] * 64.0, 1.0),
+       # share of the SIMDs' issue cycles taken by vector ALU instructions: a wave64 instruction occupies its 16-lane SIMD for
+       # 4 cycles; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
+       "valu_issue_busy": summary["SQ_INSTS_VALU"] * 4.0 / max(1024.0 * summary["GRBM_GUI_ACTIVE"] / 8.0, 1.0),
+       "valu_instructions_per_launch": summary["SQ_INSTS_VALU"],
        "source": "rocprofv3 --pmc, separate passes (tools/profile_pmc.sh), mean over the renderKernel<false> dispatches"}
 print(json.dumps(out, indent=1))
