@@ -48,6 +48,7 @@ def lib():
     L.rt_get_scene_info.argtypes = [vp, C.POINTER(T.SceneInfo)]
     L.rt_profile_waves.argtypes = [vp, i32, i32, vp, sz, C.POINTER(sz)]
     L.rt_validate_scene_host.argtypes = [C.POINTER(T.SceneDesc), C.POINTER(T.SceneInfo)]
+    L.rt_validate_scene_device.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
     L.rt_camera_look.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.POINTER(T.Camera)]
     L.rt_bake_model.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, C.POINTER(C.c_float), i32,
                                 vp, vp, vp, vp, vp, C.POINTER(C.c_int32)]
@@ -133,6 +134,10 @@ class Renderer:
         n = C.c_size_t(0)
         _check(lib().rt_profile_waves(self._ctx, width, height, buf.ctypes.data, cap, C.byref(n)))
         return buf[:n.value]
+
+    def validate_device_scene(self, scene_desc):
+        """Checks the octree arrays resident on the GPU against the scene they were uploaded from (raises on violation)."""
+        _check(lib().rt_validate_scene_device(self._ctx, C.byref(scene_desc)))
 
     def scene_info(self):
         info = T.SceneInfo()

@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "rt_build.h"
 #include "rt_device_types.h"
 #include "rt_kernels.h"
 #include "rt_scene.h"
@@ -73,6 +74,10 @@ struct rt_ctx {
     int costSlot = 0;
     long long orderKey = -1;
     bool costOrdering = true;
+    bool forceDeviceBuild = false;   // RT_DEVICE_BUILD=1: build every scene's octrees on the GPU
+    // what rt_validate_scene_device needs besides the device arrays
+    std::vector<uint32_t> mdlInfoHost;
+    int64_t nodeFloat4s = 0, triFloat4s = 0;
 };
 
 namespace {
@@ -216,6 +221,7 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     c->device = devices[0];
     if (const char* e = std::getenv("RT_BLOCK_ORDER")) c->blockOrder = std::atoi(e);   // experiment switches
     if (const char* e = std::getenv("RT_COST_ORDER")) c->costOrdering = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_DEVICE_BUILD")) c->forceDeviceBuild = std::atoi(e) != 0;
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, sizeof(unsigned long long) * rt::kCntCount);
     if (e != hipSuccess) { delete c; return failHip(e, "hipMalloc(counters)"); }
@@ -250,9 +256,10 @@ void rt_destroy(rt_ctx* ctx) {
 
 int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
     if (!ctx || !scene) return fail(RT_ERR_INVALID, "null argument");
+    const bool onDevice = scene->buildOnDevice != 0 || ctx->forceDeviceBuild;
     rt::FlatScene flat;
     std::string err;
-    if (!rt::flattenScene(*scene, flat, err)) return fail(RT_ERR_INVALID, err);
+    if (!rt::flattenScene(*scene, flat, err, onDevice)) return fail(RT_ERR_INVALID, err);
 
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipDeviceSynchronize());
@@ -268,12 +275,32 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
         (rc = uploadArray(flat.mdlGateMin, &d.mdlGateMin, A, bytes)) || (rc = uploadArray(flat.mdlGateMax, &d.mdlGateMax, A, bytes)) ||
         (rc = uploadArray(flat.mdlTightMin, &d.mdlTightMin, A, bytes)) || (rc = uploadArray(flat.mdlTightMax, &d.mdlTightMax, A, bytes)) ||
         (rc = uploadArray(flat.mdlMat, &d.mdlMat, A, bytes)) || (rc = uploadArray(flat.mdlInfo, &d.mdlInfo, A, bytes)) ||
-        (rc = uploadArray(flat.mdlChunkMin, &d.mdlChunkMin, A, bytes)) || (rc = uploadArray(flat.mdlChunkMax, &d.mdlChunkMax, A, bytes)) ||
-        (rc = uploadArray(flat.nodes, &d.nodes, A, bytes)) || (rc = uploadArray(flat.tris, &d.tris, A, bytes)) ||
-        (rc = uploadArray(flat.attrs, &d.attrs, A, bytes))) {
+        (rc = uploadArray(flat.mdlChunkMin, &d.mdlChunkMin, A, bytes)) || (rc = uploadArray(flat.mdlChunkMax, &d.mdlChunkMax, A, bytes))) {
         freeScene(ctx);
         return rc;
     }
+    if (onDevice && !flat.deviceModels.empty()) {
+        rt::DeviceMeshes built;
+        hipError_t e = rt::buildMeshesOnDevice(*scene, flat, built, err);
+        if (e != hipSuccess) { freeScene(ctx); return fail(e == hipErrorInvalidValue ? RT_ERR_INVALID : RT_ERR_DEVICE, err); }
+        A.push_back(built.nodes); A.push_back(built.tris); A.push_back(built.attrs);
+        d.nodes = built.nodes; d.tris = built.tris; d.attrs = built.attrs;
+        flat.nodeCount = built.nodeCount; flat.leafCount = built.leafCount;
+        flat.maxDepth = flat.forestDepth + built.depth;
+        ctx->nodeFloat4s = built.nodeCount * rt::kNodeFloat4s;
+        ctx->triFloat4s = built.triangleRecords * 3;
+        bytes += (ctx->nodeFloat4s + ctx->triFloat4s + flat.triangleCount * rt::kAttrFloat4s) * (int64_t)sizeof(rt::F4);
+        if (flat.maxDepth >= rt::kMaxOctreeDepth) { freeScene(ctx); return fail(RT_ERR_INVALID, "forest plus octree nesting exceeds the traversal stack"); }
+    } else {
+        if ((rc = uploadArray(flat.nodes, &d.nodes, A, bytes)) || (rc = uploadArray(flat.tris, &d.tris, A, bytes)) ||
+            (rc = uploadArray(flat.attrs, &d.attrs, A, bytes))) {
+            freeScene(ctx);
+            return rc;
+        }
+        ctx->nodeFloat4s = (int64_t)flat.nodes.size();
+        ctx->triFloat4s = (int64_t)flat.tris.size();
+    }
+    ctx->mdlInfoHost = flat.mdlInfo;
     d.nSph = scene->sphereCount; d.nPln = scene->planeCount; d.nBox = scene->AABBCount; d.nMdl = scene->modelCount;
     d.forestRoot = flat.forestRoot;
     std::memcpy(d.lightPos, flat.lightPos, sizeof d.lightPos);
@@ -290,6 +317,23 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
     in.sphereCount = d.nSph; in.planeCount = d.nPln; in.AABBCount = d.nBox; in.modelCount = d.nMdl;
     in.triangleCount = flat.triangleCount; in.nodeCount = flat.nodeCount; in.leafCount = flat.leafCount;
     in.maxDepth = flat.maxDepth; in.deviceBytes = bytes;
+    return RT_OK;
+}
+
+int rt_validate_scene_device(rt_ctx* ctx, const rt_scene_desc* scene) {
+    if (!ctx || !scene) return fail(RT_ERR_INVALID, "null argument");
+    if (!ctx->haveScene) return fail(RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    if ((size_t)scene->modelCount * 4 != ctx->mdlInfoHost.size()) return fail(RT_ERR_INVALID, "not the scene this context was uploaded from");
+    RT_HIP(hipSetDevice(ctx->device));
+    rt::FlatScene flat;
+    flat.mdlInfo = ctx->mdlInfoHost;
+    flat.forestRoot = ctx->scene.forestRoot;
+    flat.nodes.resize((size_t)ctx->nodeFloat4s);
+    flat.tris.resize((size_t)ctx->triFloat4s);
+    if (ctx->nodeFloat4s) RT_HIP(hipMemcpy(flat.nodes.data(), ctx->scene.nodes, flat.nodes.size() * sizeof(rt::F4), hipMemcpyDeviceToHost));
+    if (ctx->triFloat4s) RT_HIP(hipMemcpy(flat.tris.data(), ctx->scene.tris, flat.tris.size() * sizeof(rt::F4), hipMemcpyDeviceToHost));
+    std::string err;
+    if (!rt::validateFlatScene(*scene, flat, err)) return fail(RT_ERR_INVALID, err);
     return RT_OK;
 }
 

@@ -6,6 +6,8 @@
 // gate plus its linear triangle loop (Model.cpp:275-317), and the traversal kernel reproduces exactly that result.
 #include "rt_scene.h"
 
+#include "rt_node_codec.h"
+
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -123,47 +125,6 @@ void packMaterial(const rt_material& m, int objectType, uint32_t flags, F4 out[3
 
 static bool isIgnoredPosition(const rt_vec3& p) { return p.x == -999.0f && p.y == -999.0f && p.z == -999.0f; }
 
-// Writes one node record: the eight child boxes lo/hi[axis][slot] (already padded; ignored for slots in neither mask)
-// are quantised outwards against the node's own origin and power-of-two steps.
-static void writeNode(F4* rec, const float lo[3][8], const float hi[3][8], const uint32_t leafRef[8], uint32_t childBase,
-                      uint32_t imask, uint32_t lmask, uint32_t model) {
-    const uint32_t used = imask | lmask;
-    float origin[3] = {0.0f, 0.0f, 0.0f};
-    uint32_t expo[3] = {127u, 127u, 127u};
-    uint32_t planes[3][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
-    for (int a = 0; a < 3; a++) {
-        double mn = std::numeric_limits<double>::infinity(), mx = -mn;
-        for (int c = 0; c < 8; c++) {
-            if (!((used >> c) & 1u)) continue;
-            mn = std::min(mn, (double)lo[a][c]); mx = std::max(mx, (double)hi[a][c]);
-        }
-        double step = 1.0;
-        if (used) {
-            origin[a] = (float)mn;
-            int ex = -126;
-            if (mx > mn) { std::frexp((mx - mn) / 255.0, &ex); }     // 2^ex >= extent / 255
-            ex = std::min(127, std::max(-126, ex));
-            expo[a] = (uint32_t)(ex + 127);
-            step = std::ldexp(1.0, ex);
-        }
-        for (int c = 0; c < 8; c++) {
-            uint32_t ql = 255u, qh = 0u;
-            if ((used >> c) & 1u) {
-                ql = (uint32_t)std::min(255.0, std::max(0.0, std::floor(((double)lo[a][c] - (double)origin[a]) / step)));
-                qh = (uint32_t)std::min(255.0, std::max(0.0, std::ceil(((double)hi[a][c] - (double)origin[a]) / step)));
-            }
-            planes[a][c / 4] |= ql << (8 * (c % 4));
-            planes[a][2 + c / 4] |= qh << (8 * (c % 4));
-        }
-    }
-    rec[0] = f4(origin[0], origin[1], origin[2], bitsFloat(expo[0] | (expo[1] << 8) | (expo[2] << 16)));
-    rec[1] = f4(bitsFloat(childBase), bitsFloat(imask | (lmask << 8)), bitsFloat(model), 0.0f);
-    for (int a = 0; a < 3; a++) rec[2 + a] = f4(bitsFloat(planes[a][0]), bitsFloat(planes[a][1]), bitsFloat(planes[a][2]), bitsFloat(planes[a][3]));
-    rec[5] = f4(bitsFloat(leafRef[0]), bitsFloat(leafRef[1]), bitsFloat(leafRef[2]), bitsFloat(leafRef[3]));
-    rec[6] = f4(bitsFloat(leafRef[4]), bitsFloat(leafRef[5]), bitsFloat(leafRef[6]), bitsFloat(leafRef[7]));
-    rec[7] = f4(0.0f, 0.0f, 0.0f, 0.0f);
-}
-
 // Validates a model's arrays and returns the bounds of its reachable triangles and the padding of its child boxes.
 // Child boxes are padded so that the approximate slab test of the traversal can never reject a box whose
 // triangle the exact intersection routine would accept.
@@ -188,13 +149,13 @@ static bool modelBounds(const rt_model& m, int modelIndex, Box& tight, float& pa
 // Emits the octree and triangle records of one model into the shared arrays.  `rootIndex` is the node the forest
 // reserved for the model's root (unused for a model without reachable triangles); `tight` / `pad` come from modelBounds.
 static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& params, uint32_t rootIndex, const Box& tight,
-                         float pad, FlatScene& out, std::string& err) {
+                         float pad, bool onDevice, FlatScene& out, std::string& err) {
     const int64_t nTri = reachableTriangles(m.indicesCount);
-    const uint32_t triBase = (uint32_t)(out.attrs.size() / kAttrFloat4s);
+    const uint32_t triBase = (uint32_t)out.triangleCount;
 
     (void)err;
-    std::vector<BuildTri> btris((size_t)nTri);
-    for (int64_t t = 0; t < nTri; t++) {
+    std::vector<BuildTri> btris(onDevice ? 0 : (size_t)nTri);
+    for (int64_t t = 0; t < nTri && !onDevice; t++) {
         const int32_t* ix = m.indices + 3 * t;
         const rt_vertex& a = m.vertices[ix[0]];
         const rt_vertex& b = m.vertices[ix[1]];
@@ -240,8 +201,19 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
         out.mdlChunkMax.push_back(f4(m.boundingBoxes[b].max, 0.0f));
     }
 
+    if (onDevice && nTri > 0) {
+        // octree, triangle and attribute records of this model are produced on the GPU (rt_build.hip)
+        DeviceBuildModel dm;
+        dm.model = modelIndex; dm.rootIndex = rootIndex; dm.triStart = triBase; dm.triCount = (uint32_t)nTri;
+        for (int a = 0; a < 3; a++) { dm.lo[a] = tight.lo[a]; dm.hi[a] = tight.hi[a]; }
+        dm.pad = pad;
+        dm.perBoxTris = (int32_t)perBoxTris;
+        for (int b = 0; b < 8; b++) dm.chunkIndices[b] = m.boundingBoxes[b].indicesCount;
+        out.deviceModels.push_back(dm);
+    }
+
     OctreeBuilder builder(btris, params);
-    int root = builder.build();
+    int root = onDevice ? -1 : builder.build();
 
     auto emitLeaf = [&](const TreeNode& n) -> uint32_t {
         uint32_t start = (uint32_t)(out.tris.size() / 3);
@@ -273,7 +245,7 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
             for (int c = 0; c < 8; c++) for (int a = 0; a < 3; a++) { lo[a][c] = inf; hi[a][c] = -inf; }
             for (int a = 0; a < 3; a++) { lo[a][0] = tight.lo[a] - pad; hi[a][0] = tight.hi[a] + pad; }
             leafRef[0] = emitLeaf(T[root]);
-            writeNode(&out.nodes[(size_t)rootIndex * kNodeFloat4s], lo, hi, leafRef, 0u, 0u, 1u, (uint32_t)modelIndex);
+            encodeNode(&out.nodes[(size_t)rootIndex * kNodeFloat4s], lo, hi, leafRef, 0u, 0u, 1u, (uint32_t)modelIndex);
         } else {
             // breadth-first flattening: (tree node, flat node index)
             std::vector<std::pair<int, uint32_t>> queue;
@@ -299,7 +271,7 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
                     if (ch.leaf) { lmask |= 1u << c; leafRef[c] = emitLeaf(ch); }
                     else { imask |= 1u << c; queue.emplace_back(n.child[c], next++); }
                 }
-                writeNode(&out.nodes[(size_t)self * kNodeFloat4s], lo, hi, leafRef, childBase, imask, lmask,
+                encodeNode(&out.nodes[(size_t)self * kNodeFloat4s], lo, hi, leafRef, childBase, imask, lmask,
                           q == 0 ? (uint32_t)modelIndex : kNoModel);
             }
         }
@@ -319,6 +291,7 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
         out.mdlTightMin.push_back(f4(inf, inf, inf, 0.0f));
         out.mdlTightMax.push_back(f4(-inf, -inf, -inf, 0.0f));
     }
+    if (onDevice && nTri > 0) rootRef = rootIndex;
     out.mdlInfo.push_back(rootRef);
     out.mdlInfo.push_back(triBase);
     out.mdlInfo.push_back(0);
@@ -390,14 +363,14 @@ void buildForest(std::vector<ForestItem>& items, int first, int count, uint32_t 
         for (int a = 0; a < 3; a++) { lo[a][slotOf[g]] = b.lo[a]; hi[a][slotOf[g]] = b.hi[a]; }
         imask |= 1u << slotOf[g];
     }
-    writeNode(&out.nodes[(size_t)self * kNodeFloat4s], lo, hi, leafRef, childBase, imask, 0u, kNoModel);
+    encodeNode(&out.nodes[(size_t)self * kNodeFloat4s], lo, hi, leafRef, childBase, imask, 0u, kNoModel);
     // slots ascend with g, so the g-th group is the g-th internal child
     for (int g = 0; g < groups; g++) buildForest(items, groupFirst[g], groupCount[g], childBase + (uint32_t)g, depth + 1, out, rootIndex, deepest);
 }
 
 }  // namespace
 
-bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err) {
+bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err, bool meshesOnDevice) {
     out = FlatScene();
     if (s.sphereCount < 0 || s.planeCount < 0 || s.AABBCount < 0 || s.modelCount < 0) { err = "negative object count"; return false; }
     if (s.lightCount < 1 || !s.lights) { err = "scene needs at least one light (lights[0] is the only one read)"; return false; }
@@ -455,8 +428,10 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err) {
         buildForest(items, 0, (int)items.size(), 0u, 0, out, rootIndex, forestDepth);
     }
     for (int i = 0; i < s.modelCount; i++) {
-        if (!flattenModel(s.models[i], i, params, rootIndex[(size_t)i], tight[(size_t)i], pad[(size_t)i], out, err)) return false;
+        if (!flattenModel(s.models[i], i, params, rootIndex[(size_t)i], tight[(size_t)i], pad[(size_t)i], meshesOnDevice, out, err)) return false;
     }
+    out.forestDepth = forestDepth;
+    out.params = params;
     out.maxDepth += forestDepth;
     if (out.maxDepth >= kMaxOctreeDepth) { err = "forest plus octree nesting exceeds the traversal stack"; return false; }
     // one spare triangle record: the intersection loop requests record i + 1 while it works on record i
@@ -489,7 +464,11 @@ struct Walker {
             uint32_t idw, owner;
             std::memcpy(&idw, &flat.tris[(size_t)t * 3].w, 4);
             std::memcpy(&owner, &flat.tris[(size_t)t * 3 + 1].w, 4);
-            if (owner != (uint32_t)m) { err = "triangle record tagged with another model"; return false; }
+            if (owner != (uint32_t)m) {
+                err = "triangle record " + std::to_string(t) + " (leaf starting at " + std::to_string(start) + ") of model " + std::to_string(m) +
+                      " is tagged with model " + std::to_string(owner);
+                return false;
+            }
             uint32_t id = idw & kTriIdMask;
             if (id >= mine.size()) { err = "triangle id out of range"; return false; }
             if (mine[id]) { err = "triangle " + std::to_string(id) + " appears in two leaves"; return false; }
@@ -545,9 +524,15 @@ struct Walker {
             }
             if ((lmask >> c) & 1u) {
                 uint32_t ref; std::memcpy(&ref, &(&rec[5 + c / 4].x)[c % 4], 4);
-                if (!leaf(m, ref, lo, hi)) return false;
+                if (!leaf(m, ref, lo, hi)) {
+                    err += " [node " + std::to_string(index) + " slot " + std::to_string(c) + "]";
+                    return false;
+                }
             } else {
-                if (!node(next++, m, lo, hi, depth + 1)) return false;
+                if (!node(next++, m, lo, hi, depth + 1)) {
+                    err += " <- node " + std::to_string(index) + " (childBase " + std::to_string(childBase) + ", masks " + std::to_string(masks) + ", slot " + std::to_string(c) + ")";
+                    return false;
+                }
             }
         }
         return true;

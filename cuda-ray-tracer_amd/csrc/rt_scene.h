@@ -14,6 +14,17 @@ struct OctreeParams {
     int leafTriangles = 8;   // a node with at most this many triangles is a leaf (8 measured best on MI355X: 4 -> +8 % frame time, 16 -> +7 %)
 };
 
+// What the device octree builder needs to know about one model with reachable triangles.
+struct DeviceBuildModel {
+    int32_t model;
+    uint32_t rootIndex;         // node reserved for the model's root
+    uint32_t triStart, triCount;   // the model's slice of the scene-wide triangle numbering (triStart = triBase)
+    float lo[3], hi[3];         // bounds of the reachable triangles
+    float pad;                  // padding of this model's child boxes
+    int32_t perBoxTris;         // triangles per sequential chunk (eight-box mode)
+    int32_t chunkIndices[8];    // boundingBoxes[b].indicesCount
+};
+
 // Host staging copy of everything that goes to HBM.
 struct FlatScene {
     std::vector<F4> sphGeom, sphMat, plnP, plnN, plnMat, boxMin, boxMax, boxMat;
@@ -25,14 +36,19 @@ struct FlatScene {
     int64_t triangleCount = 0, nodeCount = 0, leafCount = 0;
     int maxDepth = 0;               // deepest nesting of internal nodes, forest levels included
     uint32_t forestRoot = kNoRoot;  // node the mesh traversal starts from
+    int forestDepth = 0;            // nesting levels above the model roots
+    OctreeParams params;            // the build parameters in force
+    std::vector<DeviceBuildModel> deviceModels;   // filled instead of the per-model octrees when meshes are built on the GPU
 };
 
 // Number of triangles the reference's loops visit for a model with this many indices
 // (for (i = 0; i < indicesCount - 3; i += 3), Model.cpp:282): the last triangle is never reached.
 int64_t reachableTriangles(int64_t indicesCount);
 
-// Fills `out` from `scene`.  Returns false and sets `err` if the scene fails validation.
-bool flattenScene(const rt_scene_desc& scene, FlatScene& out, std::string& err);
+// Fills `out` from `scene`.  Returns false and sets `err` if the scene fails validation.  With meshesOnDevice the
+// per-model octrees, triangle and attribute records are left out (nodes then holds only the forest above the model
+// roots and the reserved root slots) and deviceModels describes what the device builder has to produce.
+bool flattenScene(const rt_scene_desc& scene, FlatScene& out, std::string& err, bool meshesOnDevice = false);
 
 // Walks the flattened octrees of `flat` (built from `scene`) and checks the invariants the traversal kernel relies on:
 // the forest reaches every non-empty model's root exactly once; every reachable triangle of every model sits in

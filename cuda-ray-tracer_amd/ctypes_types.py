@@ -84,7 +84,7 @@ class SceneDesc(C.Structure):
                 ("AABBs", C.POINTER(AABB)), ("AABBCount", c_i32),
                 ("lights", C.POINTER(Light)), ("lightCount", c_i32),
                 ("models", C.POINTER(Model)), ("modelCount", c_i32),
-                ("octreeMaxDepth", c_i32), ("octreeLeafTriangles", c_i32)]
+                ("octreeMaxDepth", c_i32), ("octreeLeafTriangles", c_i32), ("buildOnDevice", c_i32)]
 
 
 class Dynamic(C.Structure):

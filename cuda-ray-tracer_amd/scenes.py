@@ -246,8 +246,9 @@ def get_mesh(name, detail):
     return _MESH_CACHE[key]
 
 
-def build_scene(spec, octree_max_depth=0, octree_leaf_triangles=0, meshes=None):
-    """SceneSpec -> BuiltScene.  `meshes` may map model name -> LoadedMesh to override the generators."""
+def build_scene(spec, octree_max_depth=0, octree_leaf_triangles=0, meshes=None, build_on_device=False):
+    """SceneSpec -> BuiltScene.  `meshes` may map model name -> LoadedMesh to override the generators;
+    build_on_device asks rt_upload_scene to construct the octrees on the GPU."""
     out = BuiltScene()
     d = out.desc
     sph = (T.Sphere * max(len(spec.spheres), 1))()
@@ -276,6 +277,7 @@ def build_scene(spec, octree_max_depth=0, octree_leaf_triangles=0, meshes=None):
     d.models = C.cast(mdl, C.POINTER(T.Model)); d.modelCount = len(spec.models)
     d.lights = C.cast(light, C.POINTER(T.Light)); d.lightCount = 1
     d.octreeMaxDepth = octree_max_depth; d.octreeLeafTriangles = octree_leaf_triangles
+    d.buildOnDevice = 1 if build_on_device else 0
     out.keep += [sph, pln, box, mdl, light]
     d._keepalive = out.keep      # the descriptor alone keeps its arrays alive
     out.camera = binding.camera_look(spec.cam_pos, spec.fov, spec.cam_yaw, spec.cam_pitch)

@@ -134,6 +134,13 @@ int rt_get_scene_info(rt_ctx* ctx, rt_scene_info* info);
  */
 int rt_validate_scene_host(const rt_scene_desc* scene, rt_scene_info* info);
 
+/*
+ * Copies the node and triangle arrays of the uploaded scene back from the GPU and runs the same checks on them against
+ * `scene`, which must be the description the context was uploaded from.  This is how a GPU-built octree
+ * (rt_scene_desc.buildOnDevice) is verified.  Blocking.  No reference counterpart.
+ */
+int rt_validate_scene_device(rt_ctx* ctx, const rt_scene_desc* scene);
+
 /* Message describing the last failure on this thread ("" if none). */
 const char* rt_last_error(void);
 

@@ -159,6 +159,9 @@ typedef struct rt_scene_desc {
     /* Octree build parameters (0 = library default: depth 8, 8 triangles per leaf). */
     int32_t octreeMaxDepth;
     int32_t octreeLeafTriangles;
+    /* 0: the octrees are built on the host; 1: on the GPU (Morton sort, one launch per level) - same device layout,
+     * different but equally valid tree shape, identical pixels.  Meant for uploads of millions of triangles. */
+    int32_t buildOnDevice;
 } rt_scene_desc;
 
 /*

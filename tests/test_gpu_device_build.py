@@ -1,0 +1,87 @@
+"""Octrees built on the GPU (rt_scene_desc.buildOnDevice): structural validation of the arrays the builder leaves in
+device memory, and pixel parity against the host-built octree and the CPU oracle."""
+import numpy as np
+import pytest
+
+from conftest import load_package
+from helpers import MATTE, mesh_from_triangles, simple_spec
+from parity import assert_parity, compare_frames
+
+load_package()
+from cuda_ray_tracer_amd import scenes  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("leaf,depth", [(0, 0), (1, 10), (4, 3), (100000, 1)])
+def test_device_built_forest_is_valid_and_renders_the_same_frame(renderer, leaf, depth):
+    spec, cfg, w, h = scenes.config_scene(3, detail=0.3)
+    host = scenes.build_scene(spec, octree_max_depth=depth, octree_leaf_triangles=leaf)
+    renderer.upload(host.desc)
+    renderer.set_state(host.camera, cfg)
+    renderer.validate_device_scene(host.desc)                      # the check itself, on a host-built scene
+    rgb0, ids0, t0, st0 = renderer.render_ids(320, 180)
+    info0 = renderer.scene_info()
+
+    dev = scenes.build_scene(spec, octree_max_depth=depth, octree_leaf_triangles=leaf, build_on_device=True)
+    renderer.upload(dev.desc)
+    renderer.set_state(dev.camera, cfg)
+    renderer.validate_device_scene(dev.desc)
+    info = renderer.scene_info()
+    assert info.triangleCount == info0.triangleCount and info.nodeCount >= 4 and info.leafCount >= 3
+    assert info.maxDepth <= (depth or 8) + 1
+    rgb, ids, t, st = renderer.render_ids(320, 180)
+    assert np.array_equal(rgb, rgb0) and np.array_equal(ids, ids0) and np.array_equal(t.view(np.uint32), t0.view(np.uint32))
+    assert st.rays == st0.rays
+
+
+def test_device_build_against_the_oracle_all_mesh_modes(renderer, oracle):
+    spec, cfg, w, h = scenes.config_scene(2, detail=0.3)
+    built = scenes.build_scene(spec, build_on_device=True)
+    renderer.upload(built.desc)
+    for mode in ("boundingBox", "eightBoundingBoxes", "none"):
+        cfg.boundingBox = int(mode == "boundingBox"); cfg.eightBoundingBoxes = int(mode == "eightBoundingBoxes")
+        renderer.set_state(built.camera, cfg)
+        g_rgb, g_ids, g_t, st = renderer.render_ids(256, 144)
+        o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built.desc, built.camera, cfg, 256, 144, threads=16)
+        stats = compare_frames(g_rgb, g_ids, g_t, o_rgb, o_ids, o_t, None)
+        print(mode, stats)
+        assert_parity(stats, st.rays, o_rays)
+        assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+
+
+def test_device_build_degenerate_models(renderer, oracle):
+    """Empty model, one reachable triangle, coincident triangles (identical Morton codes), many models with a forest."""
+    tri = [[-1, -1, -5], [1, -1, -5], [0, 1, -5]]
+    small = [[-0.3, -0.3, 0], [0.3, -0.3, 0], [0, 0.3, 0]]
+    meshes = {"empty": mesh_from_triangles([tri]), "one": mesh_from_triangles([tri, tri]), "stack": mesh_from_triangles([tri] * 40),
+              "t": mesh_from_triangles([small] * 5)}
+    models = [scenes.ModelSpec("empty", (0, 0, 0), 1, MATTE), scenes.ModelSpec("one", (3, 0, -2), 1, MATTE),
+              scenes.ModelSpec("stack", (-3, 0, -2), 1, MATTE)]
+    models += [scenes.ModelSpec("t", (i % 6 - 2.5, i // 6 - 1.5, -6 - (i % 3)), 1, MATTE) for i in range(24)]
+    spec = simple_spec(models=models)
+    cfg = scenes.default_config()
+    built = scenes.build_scene(spec, meshes=meshes, octree_leaf_triangles=2, build_on_device=True)
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    renderer.validate_device_scene(built.desc)
+    g_rgb, g_ids, g_t, st = renderer.render_ids(192, 108)
+    o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built.desc, built.camera, cfg, 192, 108, threads=16)
+    stats = compare_frames(g_rgb, g_ids, g_t, o_rgb, o_ids, o_t, None)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+    assert (g_ids[..., 0] >> 24 == 4).sum() > 50        # meshes are actually visible
+
+
+def test_device_build_many_models_config5(renderer, oracle):
+    spec, cfg, w, h = scenes.config_scene(5, detail=0.15)
+    built = scenes.build_scene(spec, build_on_device=True)
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    renderer.validate_device_scene(built.desc)
+    window = (120, 60, 200, 100)
+    g_rgb, g_ids, g_t, st = renderer.render_ids(320, 180)
+    o_rgb, o_ids, o_t, _, _ = oracle.render(built.desc, built.camera, cfg, 320, 180, window=window, threads=16)
+    stats = compare_frames(g_rgb, g_ids, g_t, o_rgb, o_ids, o_t, window)
+    assert_parity(stats)
+    assert stats["id_mismatch"] == 0
