@@ -74,10 +74,6 @@ struct rt_ctx {
     int costSlot = 0;
     long long orderKey = -1;
     bool costOrdering = true;
-    // persistent-wave renderer for plain frames (RT_PERSIST=0 falls back to one wave per 8x8 block)
-    bool persistent = true;
-    int residentWaves = 0, advanceThreshold = 16;
-    void* dQueues = nullptr;
     bool forceDeviceBuild = false;   // RT_DEVICE_BUILD=1: build every scene's octrees on the GPU
     // what rt_validate_scene_device needs besides the device arrays
     std::vector<uint32_t> mdlInfoHost;
@@ -142,10 +138,8 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
                   bool instrumented, hipStream_t stream, unsigned long long* waveClocks = nullptr) {
     const DispatchPlan plan = planDispatch(ctx, frame);
     const rt::FrameParams& p = plan.p;
-    const bool persist = ctx->persistent && !instrumented && !ids && !tbuf && !waveClocks && ctx->residentWaves > 0;
     if (!plan.ordered) {
-        if (persist) RT_HIP(rt::launchPersist(ctx->scene, p, out, counters, stream, nullptr, nullptr, ctx->dQueues, ctx->residentWaves, ctx->advanceThreshold));
-        else RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks));
+        RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks));
         return RT_OK;
     }
     // Two cost buffers: this frame accumulates into `cur`; the ranking pass that follows reads it and clears `nxt`, which the
@@ -153,13 +147,8 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
     if (!plan.haveOrder) RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2, stream));
     uint32_t* cur = ctx->dTileCost + (size_t)ctx->costSlot * kMaxOrderedTiles;
     uint32_t* nxt = ctx->dTileCost + (size_t)(ctx->costSlot ^ 1) * kMaxOrderedTiles;
-    if (persist) {
-        RT_HIP(rt::launchPersist(ctx->scene, p, out, counters, stream, plan.haveOrder ? ctx->dTileOrder : nullptr, cur, ctx->dQueues,
-                                 ctx->residentWaves, ctx->advanceThreshold));
-    } else {
-        RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks,
-                                plan.haveOrder ? ctx->dTileOrder : nullptr, cur));
-    }
+    RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks,
+                            plan.haveOrder ? ctx->dTileOrder : nullptr, cur));
     RT_HIP(rt::launchRankTiles(cur, ctx->dTileOrder, nxt, p.ownedTiles, stream));
     ctx->costSlot ^= 1;
     ctx->orderKey = plan.key;
@@ -233,10 +222,6 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     if (const char* e = std::getenv("RT_BLOCK_ORDER")) c->blockOrder = std::atoi(e);   // experiment switches
     if (const char* e = std::getenv("RT_COST_ORDER")) c->costOrdering = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_DEVICE_BUILD")) c->forceDeviceBuild = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RT_PERSIST")) c->persistent = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RT_ADVANCE_THRESHOLD")) { const int v = std::atoi(e); if (v >= 1 && v <= 64) c->advanceThreshold = v; }
-    c->residentWaves = rt::persistResidentWaves();
-    if (const char* e = std::getenv("RT_PERSIST_WAVES")) { const int v = std::atoi(e); if (v >= 8) c->residentWaves = v; }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, sizeof(unsigned long long) * rt::kCntCount);
     if (e != hipSuccess) { delete c; return failHip(e, "hipMalloc(counters)"); }
@@ -245,7 +230,6 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles * 2);
     if (e == hipSuccess) { c->dTileCost = static_cast<uint32_t*>(q); e = hipMemset(q, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2); }
     if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles); if (e == hipSuccess) c->dTileOrder = static_cast<uint32_t*>(q); }
-    if (e == hipSuccess) { e = hipMalloc(&q, 64); if (e == hipSuccess) c->dQueues = q; }
     if (e != hipSuccess) { rt_destroy(c); return failHip(e, "hipMalloc(tile order)"); }
     e = hipEventCreate(&c->evStart);
     if (e == hipSuccess) e = hipEventCreate(&c->evStop);
@@ -265,7 +249,6 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->dCounters) (void)hipFree(ctx->dCounters);
     if (ctx->dTileCost) (void)hipFree(ctx->dTileCost);
     if (ctx->dTileOrder) (void)hipFree(ctx->dTileOrder);
-    if (ctx->dQueues) (void)hipFree(ctx->dQueues);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     delete ctx;

@@ -15,12 +15,6 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
                         unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks = nullptr,
                         const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr);
 
-// The persistent-wave renderer (plain frames only: no ids, hit distances or instrumentation).  `queues` is 32 bytes of
-// device memory that the call clears; residentWaves comes from persistResidentWaves() on the same device.
-hipError_t launchPersist(const DevScene& S, const FrameParams& P, uint8_t* out, unsigned long long* counters, hipStream_t stream,
-                         const uint32_t* tileOrder, uint32_t* tileCost, void* queues, int residentWaves, int advanceThreshold);
-int persistResidentWaves();
-
 // order = this rank's tiles sorted by descending cost (ties by index); clearNext[0..n) is zeroed for a later frame.
 hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, uint32_t* clearNext, int n, hipStream_t stream);
 

@@ -814,8 +814,6 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
 
 // order[rank of tile i by descending cost, ties by index] = i.  One wave per tile, lanes share the n comparisons
 // (n is a few hundred tiles at 1080p, 8160 at 8K).  Also clears the other cost buffer for the frame after next.
-#include "rt_persist.inc"
-
 __global__ __launch_bounds__(64) void rankTilesKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
                                                       uint32_t* __restrict__ clearNext, int n) {
     const int i = blockIdx.x;
@@ -868,27 +866,6 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
     dim3 grid(launchGridBlocks(P)), block(kBlockThreads);
     if (stats) hipLaunchKernelGGL(renderKernel<true>, grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost);
     else hipLaunchKernelGGL(renderKernel<false>, grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost);
-    return hipGetLastError();
-}
-
-int persistResidentWaves() {
-    int device = 0, cus = 0, perCu = 0;
-    if (hipGetDevice(&device) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, persistKernel, 64, 0) != hipSuccess) return 0;
-    return cus * perCu;
-}
-
-hipError_t launchPersist(const DevScene& S, const FrameParams& P, uint8_t* out, unsigned long long* counters, hipStream_t stream,
-                         const uint32_t* tileOrder, uint32_t* tileCost, void* queues, int residentWaves, int advanceThreshold) {
-    if (P.ownedTiles <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(queues, 0, sizeof(PersistQueues), stream);
-    if (e != hipSuccess) return e;
-    const unsigned blocks = (unsigned)P.ownedTiles * (unsigned)kWavesPerTile;
-    unsigned waves = (unsigned)residentWaves < blocks ? (unsigned)residentWaves : blocks;
-    waves = (waves + 7u) / 8u * 8u;     // every XCD gets the same number of waves
-    hipLaunchKernelGGL(persistKernel, dim3(waves), dim3(64), 0, stream, S, P, out, counters, tileOrder, tileCost,
-                       static_cast<PersistQueues*>(queues), advanceThreshold);
     return hipGetLastError();
 }
 
