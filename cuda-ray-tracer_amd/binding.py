@@ -128,9 +128,9 @@ class Renderer:
                                       C.c_void_p(stream or 0)))
 
     def profile_waves(self, width, height):
-        """Per-wave diagnostic records of one instrumented frame: uint64 array [waves, 10] (see rt_profile_waves)."""
+        """Per-wave diagnostic records of one instrumented frame: uint64 array [waves, 18] (see rt_profile_waves)."""
         cap = ((width + 63) // 64) * ((height + 63) // 64 + 1) * 16 * 4 + 8 * 64
-        buf = np.zeros((cap, 10), np.uint64)
+        buf = np.zeros((cap, 18), np.uint64)
         n = C.c_size_t(0)
         _check(lib().rt_profile_waves(self._ctx, width, height, buf.ctypes.data, cap, C.byref(n)))
         return buf[:n.value]

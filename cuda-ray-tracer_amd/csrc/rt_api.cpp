@@ -417,11 +417,11 @@ int rt_profile_waves(rt_ctx* ctx, int width, int height, uint64_t* clocks_out, s
     rc = ensureCapacity(&ctx->dFrame, &ctx->frameCap, (size_t)width * (size_t)height * 3);
     if (rc) return rc;
     void* d = nullptr;
-    RT_HIP(hipMalloc(&d, waves * 10 * sizeof(uint64_t)));
+    RT_HIP(hipMalloc(&d, waves * RT_WAVE_RECORD_WORDS * sizeof(uint64_t)));
     hipError_t e = hipSuccess;
     rc = launchOrdered(ctx, p, ctx->dFrame, nullptr, nullptr, nullptr, true, nullptr, static_cast<unsigned long long*>(d));
     if (rc) { (void)hipFree(d); return rc; }
-    if (e == hipSuccess) e = hipMemcpy(clocks_out, d, waves * 10 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+    if (e == hipSuccess) e = hipMemcpy(clocks_out, d, waves * RT_WAVE_RECORD_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return failHip(e, "rt_profile_waves");
     return RT_OK;

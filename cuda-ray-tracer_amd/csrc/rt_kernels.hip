@@ -27,6 +27,7 @@ typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 
 #define RT_DEV __device__ __forceinline__
 constexpr int kBlockThreads = 64;   // render workgroups are single waves
+constexpr int kWaveRecordWords = 18; // per-wave diagnostic record: start, end, 8 x (cycles, executions)
 #define FAR_T 999.0f
 
 struct V3 { float x, y, z; };
@@ -594,7 +595,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px
         cnt.rays++;
         Closest h; h.t = FAR_T; h.kind = KIND_NONE; h.idx = -1; h.tri = -1; h.u = 0; h.v = 0;
         const bool planesRun = (level == 0) || reflectPlanes;
-        traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h);
+        { SectionTimer<STATS> tm; traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h); tm.stop(stk, 4); }
         if (modelsVisible) {
             // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
             traceModels<false, STATS>(S, ro, rdir, cull, (level & 1) != 0, P.meshMode, h, stk, cnt);
@@ -603,6 +604,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px
         V3 colour = background;
         bool next = false;
         if (h.kind != KIND_NONE) {
+            SectionTimer<STATS> tmShade;
             Surface s = resolveSurface<STATS>(S, ro, rdir, h, renormCount(h.kind, planesRun, boxesRun, modelsRun), cnt);
             const bool isDebug = (s.mat.flags & 1u) != 0;
             if (level == 0 && isDebug) {
@@ -610,6 +612,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px
             } else {
                 V3 nLight = (level == 0 && h.kind == KIND_BOX) ? s.normal : normalise(s.normal);   // kernels.cu:240-245
                 colour = lighting(s.mat, lightPos, lightCol, s.point, eye, nLight, P, px, py);
+                tmShade.stop(stk, 5);
                 V3 biased = s.point + s.normal * P.shadowBias;
                 V3 toLight = normalise(lightPos - s.point);
                 bool wantNext;
@@ -641,8 +644,10 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px
                             sd = normalise(lightPoint - s.point);
                         }
                         cnt.rays++;
+                        SectionTimer<STATS> tmSh;
                         const bool bySphere = shadowSpheres(S, biased, sd);
                         const bool byBox = (hard && bySphere) ? false : shadowBoxes(S, biased, sd);
+                        tmSh.stop(stk, 6);
                         bool byModel = false;
                         if ((P.flags & kCfgModelsVisible) && !(hard && (bySphere || byBox))) {   // the shadow traces ignore renderModels (kernels.cu:304)
                             Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
@@ -721,10 +726,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     const unsigned long long cyclesStart = tileCost ? __builtin_readcyclecounter() : 0ull;
     __shared__ uint32_t stackBase[kMaxOctreeDepth * kBlockThreads];
     __shared__ uint32_t stackMask[kMaxOctreeDepth * kBlockThreads];
-    __shared__ unsigned long long profile[8];   // section accumulators of the instrumented kernel
+    __shared__ unsigned long long profile[16];  // section accumulators of the instrumented kernel: (cycles, executions) x 8
     const uint32_t lane = threadIdx.x;
     StackRef stk; stk.base = stackBase + lane; stk.mask = stackMask + lane; stk.prof = profile;
-    if (STATS) { if (lane < 8) profile[lane] = 0; __syncthreads(); }
+    if (STATS) { if (lane < 16) profile[lane] = 0; __syncthreads(); }
 
     // Workgroup B runs on XCD B % 8 (round-robin dispatch).  XCD x takes the tiles at positions x, x + 8, x + 16, ... of the
     // tile sequence: the 64 waves of a tile share one L2, and every XCD gets the same mix of cheap and expensive tiles.
@@ -735,7 +740,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
         inTile = i % kWavesPerTile;
         if (localTile >= (uint32_t)P.ownedTiles) {
             if (STATS && waveClocks && lane == 0) {
-                for (int k = 0; k < 10; k++) waveClocks[10 * (size_t)blockIdx.x + k] = 0;
+                for (int k = 0; k < kWaveRecordWords; k++) waveClocks[kWaveRecordWords * (size_t)blockIdx.x + k] = 0;
             }
             return;
         }
@@ -790,10 +795,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     }
 
     if (STATS && waveClocks && lane == 0) {      // diagnostic: when this wave started and finished, and its section sums
-        unsigned long long* rec = waveClocks + 10 * (size_t)blockIdx.x;
+        unsigned long long* rec = waveClocks + kWaveRecordWords * (size_t)blockIdx.x;
         rec[0] = clockStart;
         rec[1] = __builtin_amdgcn_s_memrealtime();
-        for (int k = 0; k < 8; k++) rec[2 + k] = stk.prof[k];
+        for (int k = 0; k < 16; k++) rec[2 + k] = stk.prof[k];
     }
     if (tileCost && lane == 0) {
         const unsigned long long spent = __builtin_readcyclecounter() - cyclesStart;

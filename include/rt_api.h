@@ -116,12 +116,14 @@ int rt_untile_device(rt_ctx* ctx, int width, int height, int world, const void* 
 int rt_count_rays(rt_ctx* ctx, int width, int height, rt_frame_stats* stats);
 
 /*
- * Diagnostic: renders one frame with the instrumented kernel and returns ten 64-bit words per wave of the launch:
- * [0],[1] the 100 MHz wall-clock ticks at which it started and finished (0,0 for waves of padding workgroups);
- * [2],[3] shader cycles and iterations in octree node visits; [4],[5] in triangle tests; [6],[7] in the per-model
- * gate loop; [8],[9] unused.  Wave i is workgroup i of the launch.  capacity_pairs counts waves (records).
- * *waves_out receives the wave count.  No reference counterpart.
+ * Diagnostic: renders one frame with the instrumented kernel and returns RT_WAVE_RECORD_WORDS 64-bit words per wave of
+ * the launch: [0],[1] the 100 MHz wall-clock ticks at which it started and finished (0,0 for waves of padding
+ * workgroups); then (shader cycles, executions) pairs for eight sections: octree node visits, triangle tests, the
+ * up-front model gates, whole mesh traces, linear-table closest traces, surface + lighting, linear-table shadow tests,
+ * unused.  Wave i is workgroup i of the launch.  capacity_pairs counts waves (records).  *waves_out receives the wave
+ * count.  No reference counterpart.
  */
+#define RT_WAVE_RECORD_WORDS 18
 int rt_profile_waves(rt_ctx* ctx, int width, int height, uint64_t* clocks_out, size_t capacity_pairs, size_t* waves_out);
 
 /* Sizes of the flattened scene (blocking, host data only). */

@@ -43,6 +43,10 @@ print("heavy 1%% waves: node visits %.1f%% (%.0f iters/wave, %.0f cyc/iter), tri
     100 * sec[heavy, 4].sum() / tot_cycles[heavy].sum(), sec[heavy, 5].mean(), sec[heavy, 4].sum() / max(sec[heavy, 5].sum(), 1)))
 order = np.argsort(-dur)[:10]
 idx = np.nonzero(valid)[0][order]
+names = ["node visits", "triangle tests", "model gates", "whole mesh traces", "linear-table traces", "surface + lighting", "linear-table shadows"]
+for label, sel in (("all waves", np.ones(len(dur), bool)), ("heavy 1% waves", heavy)):
+    print(label + ": " + ", ".join("%s %.1f%% (%.0f/wave, %.0f cyc each)" % (names[k], 100 * sec[sel, 2 * k].sum() / tot_cycles[sel].sum(), sec[sel, 2 * k + 1].mean(),
+                                                                            sec[sel, 2 * k].sum() / max(sec[sel, 2 * k + 1].sum(), 1)) for k in range(7)))
 print("heavy 1%% waves: whole mesh traces %.1f%% of their time (%.0f calls/wave, %.0f cyc/call)" % (
     100 * sec[heavy, 6].sum() / tot_cycles[heavy].sum(), sec[heavy, 7].mean(), sec[heavy, 6].sum() / max(sec[heavy, 7].sum(), 1)))
 print("slowest waves (wave index, start us, dur us):", [(int(i), round(float((clk[i, 0] - t0) / 100.0), 1), round(float((clk[i, 1] - clk[i, 0]) / 100.0), 1)) for i in idx])
