@@ -129,7 +129,7 @@ class Renderer:
 
     def profile_waves(self, width, height):
         """Per-wave diagnostic records of one instrumented frame: uint64 array [waves, 18] (see rt_profile_waves)."""
-        cap = ((width + 63) // 64) * ((height + 63) // 64 + 1) * 16 * 4 + 8 * 64
+        cap = ((width + 63) // 64) * ((height + 63) // 64 + 1) * 16 * 4 + 8 * 64 + 4096    # + split waves of the heaviest blocks
         buf = np.zeros((cap, 18), np.uint64)
         n = C.c_size_t(0)
         _check(lib().rt_profile_waves(self._ctx, width, height, buf.ctypes.data, cap, C.byref(n)))

@@ -74,6 +74,16 @@ struct rt_ctx {
     int costSlot = 0;
     long long orderKey = -1;
     bool costOrdering = true;
+    // Block feedback (see rt::BlockFeedback): the heaviest 8x8 blocks of a frame are rendered by `split` waves in the next one.
+    uint32_t* dBlockCost = nullptr;   // kMaxSplitBlocks
+    uint32_t* dExtraMap = nullptr;    // kMaxExtraWaves
+    uint32_t* dHeavyBits = nullptr;   // kMaxSplitBlocks / 32
+    int split = 1;                    // 0 disables splitting
+    int splitRatio256 = 256;          // a block is split if it costs more than this share (in 1/256) of the evenly spread frame time
+    uint32_t splitFloor = 1500;       // ... and at least this much (wave cycles / 64)
+    int residentWaves = 0;
+    hipStream_t wideStream = nullptr;  // the split waves run beside the regular ones
+    hipEvent_t evFork = nullptr, evJoin = nullptr;
     bool forceDeviceBuild = false;   // RT_DEVICE_BUILD=1: build every scene's octrees on the GPU
     // what rt_validate_scene_device needs besides the device arrays
     std::vector<uint32_t> mdlInfoHost;
@@ -116,6 +126,7 @@ rt::FrameParams frameFor(const rt_ctx* ctx, int width, int height, int rank, int
     p.ownedTiles = ownedTileCount(p.tilesX * p.tilesY, rank, world);
     p.compactOutput = compact ? 1 : 0;
     p.blockOrder = ctx->blockOrder;
+    p.split = 0;
     return p;
 }
 
@@ -134,6 +145,16 @@ DispatchPlan planDispatch(const rt_ctx* ctx, const rt::FrameParams& p) {
     return d;
 }
 
+// Frame parameters as launchOrdered will launch them: blocks are split only on top of an existing tile order.
+rt::FrameParams launchParams(const rt_ctx* ctx, const DispatchPlan& plan, bool* feedbackOut = nullptr) {
+    rt::FrameParams launch = plan.p;
+    const int blocks = plan.p.ownedTiles * (RT_TILE / 8) * (RT_TILE / 8);
+    const bool feedback = plan.ordered && ctx->split > 0 && blocks <= rt::kMaxSplitBlocks;
+    launch.split = (feedback && plan.haveOrder) ? 1 : 0;
+    if (feedbackOut) *feedbackOut = feedback;
+    return launch;
+}
+
 int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32_t* ids, float* tbuf, unsigned long long* counters,
                   bool instrumented, hipStream_t stream, unsigned long long* waveClocks = nullptr) {
     const DispatchPlan plan = planDispatch(ctx, frame);
@@ -144,12 +165,33 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
     }
     // Two cost buffers: this frame accumulates into `cur`; the ranking pass that follows reads it and clears `nxt`, which the
     // next frame accumulates into.  A change of frame geometry starts over from cleared buffers and plain tile order.
-    if (!plan.haveOrder) RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2, stream));
+    const int blocks = p.ownedTiles * (RT_TILE / 8) * (RT_TILE / 8);
+    bool feedback = false;
+    const rt::FrameParams launch = launchParams(ctx, plan, &feedback);
+    if (!plan.haveOrder) {
+        RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2, stream));
+        if (feedback) RT_HIP(hipMemsetAsync(ctx->dBlockCost, 0, sizeof(uint32_t) * (size_t)blocks, stream));
+    }
     uint32_t* cur = ctx->dTileCost + (size_t)ctx->costSlot * kMaxOrderedTiles;
     uint32_t* nxt = ctx->dTileCost + (size_t)(ctx->costSlot ^ 1) * kMaxOrderedTiles;
-    RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks,
-                            plan.haveOrder ? ctx->dTileOrder : nullptr, cur));
+    rt::BlockFeedback fb{nullptr, nullptr, nullptr};
+    if (feedback) {
+        fb.blockCost = ctx->dBlockCost;
+        if (launch.split) { fb.extraMap = ctx->dExtraMap; fb.heavyBits = ctx->dHeavyBits; }
+    }
+    if (launch.split) {
+        // fork: the split waves of the heaviest blocks start first, on their own stream, and run beside the regular waves
+        RT_HIP(hipEventRecord(ctx->evFork, stream));
+        RT_HIP(hipStreamWaitEvent(ctx->wideStream, ctx->evFork, 0));
+        unsigned long long* wideClocks = waveClocks ? waveClocks + (size_t)rt::launchGridBlocks(launch) * RT_WAVE_RECORD_WORDS : nullptr;
+        RT_HIP(rt::launchRenderWide(ctx->scene, launch, out, ids, tbuf, counters, instrumented, ctx->wideStream, wideClocks, cur, fb));
+        RT_HIP(hipEventRecord(ctx->evJoin, ctx->wideStream));
+    }
+    RT_HIP(rt::launchRender(ctx->scene, launch, out, ids, tbuf, counters, instrumented, stream, waveClocks,
+                            plan.haveOrder ? ctx->dTileOrder : nullptr, cur, fb));
+    if (launch.split) RT_HIP(hipStreamWaitEvent(stream, ctx->evJoin, 0));
     RT_HIP(rt::launchRankTiles(cur, ctx->dTileOrder, nxt, p.ownedTiles, stream));
+    if (feedback) RT_HIP(rt::launchSelectHeavy(ctx->dBlockCost, ctx->dExtraMap, ctx->dHeavyBits, blocks, ctx->residentWaves, ctx->splitRatio256, ctx->splitFloor, stream));
     ctx->costSlot ^= 1;
     ctx->orderKey = plan.key;
     return RT_OK;
@@ -222,6 +264,20 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     if (const char* e = std::getenv("RT_BLOCK_ORDER")) c->blockOrder = std::atoi(e);   // experiment switches
     if (const char* e = std::getenv("RT_COST_ORDER")) c->costOrdering = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_DEVICE_BUILD")) c->forceDeviceBuild = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_SPLIT")) c->split = std::atoi(e) != 0 ? 1 : 0;
+    if (const char* e = std::getenv("RT_SPLIT_RATIO")) { const int v = std::atoi(e); if (v >= 0 && v <= 65536) c->splitRatio256 = v; }
+    c->residentWaves = rt::residentRenderWaves();
+    if (c->residentWaves <= 0) c->split = 0;
+    if (c->split) {
+        // highest priority: the split waves must get wave slots ahead of the regular waves of the same frame
+        int leastPriority = 0, greatestPriority = 0;
+        hipError_t se = hipDeviceGetStreamPriorityRange(&leastPriority, &greatestPriority);
+        if (se == hipSuccess) se = hipStreamCreateWithPriority(&c->wideStream, hipStreamNonBlocking, greatestPriority);
+        if (se == hipSuccess) se = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming);
+        if (se == hipSuccess) se = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming);
+        if (se != hipSuccess) { const int rc = failHip(se, "stream for split waves"); rt_destroy(c); return rc; }
+    }
+    if (const char* e = std::getenv("RT_SPLIT_FLOOR")) { const int v = std::atoi(e); if (v >= 0) c->splitFloor = (uint32_t)v; }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, sizeof(unsigned long long) * rt::kCntCount);
     if (e != hipSuccess) { delete c; return failHip(e, "hipMalloc(counters)"); }
@@ -230,6 +286,9 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles * 2);
     if (e == hipSuccess) { c->dTileCost = static_cast<uint32_t*>(q); e = hipMemset(q, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2); }
     if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles); if (e == hipSuccess) c->dTileOrder = static_cast<uint32_t*>(q); }
+    if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * rt::kMaxSplitBlocks); if (e == hipSuccess) c->dBlockCost = static_cast<uint32_t*>(q); }
+    if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * rt::kMaxExtraWaves); if (e == hipSuccess) c->dExtraMap = static_cast<uint32_t*>(q); }
+    if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * (rt::kMaxSplitBlocks / 32)); if (e == hipSuccess) c->dHeavyBits = static_cast<uint32_t*>(q); }
     if (e != hipSuccess) { rt_destroy(c); return failHip(e, "hipMalloc(tile order)"); }
     e = hipEventCreate(&c->evStart);
     if (e == hipSuccess) e = hipEventCreate(&c->evStop);
@@ -249,6 +308,12 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->dCounters) (void)hipFree(ctx->dCounters);
     if (ctx->dTileCost) (void)hipFree(ctx->dTileCost);
     if (ctx->dTileOrder) (void)hipFree(ctx->dTileOrder);
+    if (ctx->dBlockCost) (void)hipFree(ctx->dBlockCost);
+    if (ctx->dExtraMap) (void)hipFree(ctx->dExtraMap);
+    if (ctx->dHeavyBits) (void)hipFree(ctx->dHeavyBits);
+    if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
+    if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
+    if (ctx->wideStream) (void)hipStreamDestroy(ctx->wideStream);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     delete ctx;
@@ -411,7 +476,8 @@ int rt_profile_waves(rt_ctx* ctx, int width, int height, uint64_t* clocks_out, s
     if (!clocks_out || !waves_out) return fail(RT_ERR_INVALID, "null argument");
     RT_HIP(hipSetDevice(ctx->device));
     rt::FrameParams p = frameFor(ctx, width, height, 0, 1, false);
-    const size_t waves = (size_t)rt::launchGridBlocks(p);
+    const rt::FrameParams planned = launchParams(ctx, planDispatch(ctx, p));
+    const size_t waves = (size_t)rt::launchGridBlocks(planned) + (planned.split ? (size_t)rt::kMaxExtraWaves : 0);
     *waves_out = waves;
     if (capacity_pairs < waves) return fail(RT_ERR_CAPACITY, "clock buffer too small");
     rc = ensureCapacity(&ctx->dFrame, &ctx->frameCap, (size_t)width * (size_t)height * 3);

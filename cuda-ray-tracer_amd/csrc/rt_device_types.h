@@ -92,6 +92,7 @@ struct FrameParams {
     int32_t rank, world, tilesX, tilesY, ownedTiles;
     int32_t compactOutput;     // 1: write tile-major into the rank's compact buffer, 0: row-major full frame
     int32_t blockOrder;        // workgroup -> tile mapping: 0 tile by tile, 2 tiles interleaved over the XCDs
+    int32_t split;             // 1: the grid starts with kMaxExtraWaves workgroups for split blocks (BlockFeedback::extraMap)
     float camPos[3], camUp[3], camRight[3], camDir[3], fovFactor;
     // SceneConfig
     float shadowBias, shadowIntensity;
@@ -116,6 +117,20 @@ enum : int32_t {
     kMeshEightBoxes = 1, // eight chunk-box gates, last slot of each chunk skipped, t > 0 (Model.cpp:220-274)
     kMeshNoBox = 2       // no gate and no t > 0 test (Model.cpp:318-356)
 };
+
+// Feedback from one frame to the next of the same geometry.  The frame is as long as its slowest wave, and a handful of
+// 8x8 pixel blocks (reflective silhouettes) run ten times longer than the rest: every block records its cost, a small
+// kernel compares each block with the time the whole frame would need if its work were spread evenly, and the next
+// frame renders the blocks that are worth it with eight waves each (one per pixel row, eight lanes per ray), started
+// before everything else.
+struct BlockFeedback {
+    uint32_t* blockCost;       // per block (tile * 64 + block in tile): cost recorded by the frame being rendered
+    const uint32_t* extraMap;  // kMaxExtraWaves entries: block | pixel row << 20, or kNoExtraWave
+    const uint32_t* heavyBits; // one bit per block: set = rendered by split waves, the regular wave skips it
+};
+constexpr int kMaxExtraWaves = 4096;
+constexpr uint32_t kNoExtraWave = 0xFFFFFFFFu;
+constexpr int kMaxSplitBlocks = 1 << 20;    // frames with more blocks per rank are rendered without splitting
 
 // Per-launch counters (one 64-bit word each), accumulated with one atomic per wave.
 enum { kCntRays = 0, kCntNodeTests, kCntTriTests, kCntAttrFetches, kCntGateTests, kCntCount };

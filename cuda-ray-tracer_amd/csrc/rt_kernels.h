@@ -13,7 +13,20 @@ namespace rt {
 // compact tile buffer (P.compactOutput).  ids / tbuf / counters may be null.  stats selects the instrumented kernel.
 hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
                         unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks = nullptr,
-                        const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr);
+                        const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr, BlockFeedback fb = BlockFeedback{nullptr, nullptr, nullptr});
+
+// The split waves of the frame's heaviest blocks (fb.extraMap), kMaxExtraWaves workgroups; meant to run concurrently with
+// launchRender of the same frame on another stream.  waveClocks, if given, receives kMaxExtraWaves records.
+hipError_t launchRenderWide(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
+                            unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
+                            uint32_t* tileCost, BlockFeedback fb);
+
+// Block feedback between frames (see BlockFeedback): chooses the blocks the next frame renders with split waves and
+// clears blockCost.  slots = waves resident on the device at once (residentRenderWaves()); a block is split if it costs
+// more than ratio256 / 256 of the frame's evenly spread time, and at least floorCost.
+hipError_t launchSelectHeavy(uint32_t* blockCost, uint32_t* extraMap, uint32_t* heavyBits, int blocks, int slots, int ratio256, uint32_t floorCost,
+                             hipStream_t stream);
+int residentRenderWaves();
 
 // order = this rank's tiles sorted by descending cost (ties by index); clearNext[0..n) is zeroed for a later frame.
 hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, uint32_t* clearNext, int n, hipStream_t stream);

@@ -27,6 +27,7 @@ typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 
 #define RT_DEV __device__ __forceinline__
 constexpr int kBlockThreads = 64;   // render workgroups are single waves
+constexpr uint32_t kSplitSpeedup = 3; // a block rendered by eight split waves is taken to finish this many times sooner
 constexpr int kWaveRecordWords = 18; // per-wave diagnostic record: start, end, 8 x (cycles, executions)
 #define FAR_T 999.0f
 
@@ -435,6 +436,193 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
     return ANYHIT ? found : false;
 }
 
+
+// The same trace for a wave in which eight consecutive lanes (a group) hold the same ray: the group visits one node at a
+// time with one child box per lane, and one leaf at a time with one triangle per lane.  All per-ray state is identical in
+// the eight lanes of a group; groups diverge from each other as lanes do in traceModels.  A single ray finishes sooner
+// this way (a node visit is ~100 instead of ~230 instructions, a leaf one step instead of up to eight), which is what
+// the handful of pixels that decide the length of a frame need; the arithmetic per box and per triangle is the same.
+template <bool ANYHIT, bool STATS>
+RT_DEV bool traceModelsWide(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, Closest& best, StackRef stk, Counters& cnt) {
+    if (S.forestRoot == kNoRoot) return false;
+    SectionTimer<STATS> timerWhole;
+    const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, slot = lane >> 3;
+    const int nMdl = S.nMdl;
+    const bool positiveOnly = meshMode != kMeshNoBox;
+    const float tmin = positiveOnly ? 0.0f : -__builtin_inff();
+    const SlabRay sr = makeSlabRay(o, d);
+    const uint32_t oct = sr.oct;
+    float bt = best.t;                            // best hit so far: (t, model, triangle), barycentrics
+    int bkind = best.kind, bmm = best.idx, bid = best.tri;
+    float bu = best.u, bv = best.v;
+
+    auto groupBits = [&](bool flag) -> uint32_t { return (uint32_t)(__ballot(flag) >> (8u * slot)) & 0xffu; };
+    auto gate = [&](int mm) -> bool {
+        if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) return false;
+        if (meshMode == kMeshWholeBox) {
+            float tGate;
+            return boxHit(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, tGate);
+        }
+        return true;
+    };
+
+    // up-front gates, eight models at a time (one per lane)
+    const bool pregated = nMdl <= kPregatedModels;
+    unsigned long long gateBits = 0;
+    if (pregated) {
+        for (int j0 = 0; j0 < nMdl; j0 += 8) {
+            const int j = j0 + (int)sub;
+            bool pass = false;
+            if (j < nMdl && tightBoxHit(xyz(ld4(S.mdlTightMin + j)), xyz(ld4(S.mdlTightMax + j)), sr, tmin, ANYHIT ? FAR_T : bt)) {
+                pass = gate(j);
+                if (STATS && meshMode == kMeshWholeBox) cnt.gateTests++;
+            }
+            gateBits |= (unsigned long long)groupBits(pass) << j0;
+        }
+        if (gateBits == 0) { timerWhole.stop(stk, 3); return false; }
+    }
+
+    uint32_t base = S.forestRoot, imask = 0, hits = 1, chunkMask = 0xffu;
+    int sp = 0;
+    uint32_t* stkBase = stk.base - sub;           // the group keeps its stack in the column of its first lane
+    uint32_t* stkMask = stk.mask - sub;
+    bool found = false;
+
+    for (;;) {
+        // ---- one node visit
+        if (hits == 0) {
+            if (sp == 0) break;
+            sp--;
+            base = stkBase[sp * kBlockThreads];
+            const uint32_t e = stkMask[sp * kBlockThreads];
+            imask = e & 0xffu; hits = e >> 8;
+        }
+        SectionTimer<STATS> timerA;
+        const uint32_t k = __builtin_ctz(hits);
+        hits &= hits - 1;
+        const uint32_t c = k ^ oct;
+        const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
+        const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
+        const u4_t head = *reinterpret_cast<const u4_t*>(np), meta = *reinterpret_cast<const u4_t*>(np + 1);
+        bool myHit;
+        {   // this lane's child: slot `sub` of the node
+            const uint32_t* planes = reinterpret_cast<const uint32_t*>(np + 2);
+            const uint32_t sh8 = 8u * (sub & 3u), dw = sub >> 2;
+            const float lx = (float)((planes[0 + dw] >> sh8) & 0xffu), hx = (float)((planes[2 + dw] >> sh8) & 0xffu);
+            const float ly = (float)((planes[4 + dw] >> sh8) & 0xffu), hy = (float)((planes[6 + dw] >> sh8) & 0xffu);
+            const float lz = (float)((planes[8 + dw] >> sh8) & 0xffu), hz = (float)((planes[10 + dw] >> sh8) & 0xffu);
+            const float sx = ubits((head.w & 0xffu) << 23) * sr.rd.x, sy = ubits(((head.w >> 8) & 0xffu) << 23) * sr.rd.y,
+                        sz = ubits(((head.w >> 16) & 0xffu) << 23) * sr.rd.z;
+            const float bx = __builtin_fmaf(ubits(head.x), sr.rd.x, -sr.ord.x), by = __builtin_fmaf(ubits(head.y), sr.rd.y, -sr.ord.y),
+                        bz = __builtin_fmaf(ubits(head.z), sr.rd.z, -sr.ord.z);
+            const float ax = __builtin_fmaf(lx, sx, bx), cx = __builtin_fmaf(hx, sx, bx);
+            const float ay = __builtin_fmaf(ly, sy, by), cy = __builtin_fmaf(hy, sy, by);
+            const float az = __builtin_fmaf(lz, sz, bz), cz = __builtin_fmaf(hz, sz, bz);
+            const float tn = fmaxf(fmaxf(fminf(ax, cx), fminf(ay, cy)), fmaxf(fminf(az, cz), tmin));
+            const float tf = fminf(fminf(fmaxf(ax, cx), fmaxf(ay, cy)), fminf(fmaxf(az, cz), ANYHIT ? FAR_T : bt));
+            myHit = tn <= tf;
+        }
+        uint32_t hmask = groupBits(myHit);
+        const uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
+        if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
+        if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
+            const int mm = (int)meta.z;
+            bool enter = pregated ? (((gateBits >> mm) & 1ull) != 0) : gate(mm);
+            if (STATS && !pregated && meshMode == kMeshWholeBox) cnt.gateTests++;
+            if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: one chunk gate per lane
+                if (STATS) cnt.gateTests += 8;
+                float tGate;
+                const bool chunkHit = boxHit(xyz(ld4(S.mdlChunkMin + 8 * mm + (int)sub)), xyz(ld4(S.mdlChunkMax + 8 * mm + (int)sub)), o, d, tGate);
+                chunkMask = groupBits(chunkHit);
+                enter = chunkMask != 0;
+            }
+            if (!enter) hmask = 0;
+        }
+        if (hits != 0) {   // keep the siblings that are still waiting
+            if (sub == 0) {
+                stkBase[sp * kBlockThreads] = base;
+                stkMask[sp * kBlockThreads] = imask | (hits << 8);
+            }
+            sp++;
+        }
+        base = meta.x;
+        imask = nodeImask;
+        hits = permuteOctants(hmask & nodeImask, oct);
+        uint32_t pend = permuteOctants(hmask & nodeLmask, oct);
+        timerA.stop(stk, 0);
+
+        // ---- the leaves this visit found: one triangle per lane, eight at a time
+        while (pend != 0) {
+            const uint32_t lc = (uint32_t)__builtin_ctz(pend) ^ oct;
+            pend &= pend - 1;
+            const uint32_t start = reinterpret_cast<const uint32_t*>(np)[20 + lc];
+            for (uint32_t chunk = 0;; chunk += 8u) {
+                SectionTimer<STATS> timerB;
+                const F4* tp = S.tris + (size_t)(start + chunk + sub) * 3;
+                const f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
+                const uint32_t idw = fbits(A.w);
+                // lanes past the end of the leaf read the triangles that follow it (or the spare records at the end of the array)
+                const uint32_t lastBits = groupBits((idw & kTriLast) != 0);
+                const bool valid = lastBits == 0 || sub <= (uint32_t)__builtin_ctz(lastBits);
+                if (STATS) cnt.triTests += lastBits == 0 ? 8u : (uint32_t)__builtin_ctz(lastBits) + 1u;
+                bool cand = false;
+                float t = 0, u = 0, v = 0;
+                int id = 0, mm = 0;
+                if (valid) {
+                    // Moeller-Trumbore exactly as the reference evaluates it (edges were subtracted on the host)
+                    V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
+                    V3 pvec = cross(d, e2);
+                    float det = dot(e1, pvec);
+                    bool rejected = (cull && det >= -0.01f) || (fabsf(det) <= 0);
+                    if (meshMode == kMeshEightBoxes) rejected = rejected || (idw & kTriChunkDropped) || !((chunkMask >> ((idw >> kTriChunkShift) & 7u)) & 1u);
+                    if (!rejected) {
+                        float invDet = 1 / det;
+                        V3 tvec = o - v0;
+                        u = dot(tvec, pvec) * invDet;
+                        if (!(u < 0 || u > 1)) {
+                            V3 qvec = cross(tvec, e1);
+                            v = dot(d, qvec) * invDet;
+                            if (!(v < 0 || u + v > 1)) {
+                                t = dot(e2, qvec) * invDet;
+                                id = (int)(idw & kTriIdMask); mm = (int)fbits(B.w);
+                                const bool inRange = !positiveOnly || t > 0;      // Model.cpp:287 vs :327
+                                if (ANYHIT) cand = t < FAR_T && inRange;
+                                else {
+                                    const bool earlier = bkind == KIND_MODEL && (mm < bmm || (mm == bmm && id < bid));
+                                    cand = inRange && (t < bt || (t == bt && earlier));
+                                }
+                            }
+                        }
+                    }
+                }
+                const uint32_t candBits = groupBits(cand);
+                if (ANYHIT) {
+                    if (candBits) { found = true; pend = 0; hits = 0; sp = 0; }
+                } else if (candBits) {
+                    // the new best = the least (t, model, triangle) among the group's candidates
+                    float rt = cand ? t : __builtin_inff();
+                    int rmm = cand ? mm : 0x7fffffff, rid = cand ? id : 0x7fffffff;
+#pragma unroll
+                    for (int off = 1; off < 8; off <<= 1) {
+                        const float ot = __shfl_xor(rt, off); const int omm = __shfl_xor(rmm, off), oid = __shfl_xor(rid, off);
+                        const bool take = ot < rt || (ot == rt && (omm < rmm || (omm == rmm && oid < rid)));
+                        if (take) { rt = ot; rmm = omm; rid = oid; }
+                    }
+                    const uint32_t winner = slot * 8u + (uint32_t)__builtin_ctz(groupBits(cand && mm == rmm && id == rid));
+                    bt = rt; bkind = KIND_MODEL; bmm = rmm; bid = rid;
+                    bu = __shfl(u, (int)winner); bv = __shfl(v, (int)winner);
+                }
+                timerB.stop(stk, 1);
+                if (lastBits != 0 || (ANYHIT && found)) break;
+            }
+        }
+        if (ANYHIT && found) break;
+    }
+    best.t = bt; best.kind = bkind; best.idx = bmm; best.tri = bid; best.u = bu; best.v = bv;
+    timerWhole.stop(stk, 3);
+    return ANYHIT ? found : false;
+}
+
 // ---------------------------------------------------------------- linear object traces
 
 // kernels.cu:67-96 over the three analytic object tables, closest hit.  skipDebug* mirror the ray types the
@@ -573,7 +761,7 @@ RT_DEV int renormCount(int kind, bool planesRun, bool boxesRun, bool modelsRun) 
 
 // Hard-shadow test of the primary level: spheres, boxes, models (kernels.cu:268-277); one ray.
 // One camera sample: kernels.cu:224-318 with the reflection chain kernels.cu:130-222 unrolled into levels.
-template <bool STATS>
+template <bool STATS, bool WIDE>
 RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px, int py, StackRef stk, Counters& cnt, Closest& primaryOut) {
     const V3 lightPos = mk(S.lightPos), lightCol = mk(S.lightCol), eye = mk(P.camPos), background = mk(P.background);
     const bool reflections = (P.flags & kCfgReflections) != 0, reflectPlanes = (P.flags & kCfgReflectPlanes) != 0;
@@ -598,7 +786,8 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px
         { SectionTimer<STATS> tm; traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h); tm.stop(stk, 4); }
         if (modelsVisible) {
             // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
-            traceModels<false, STATS>(S, ro, rdir, cull, (level & 1) != 0, P.meshMode, h, stk, cnt);
+            if (WIDE) traceModelsWide<false, STATS>(S, ro, rdir, cull, (level & 1) != 0, P.meshMode, h, stk, cnt);
+            else traceModels<false, STATS>(S, ro, rdir, cull, (level & 1) != 0, P.meshMode, h, stk, cnt);
         }
         if (level == 0) primaryOut = h;
         V3 colour = background;
@@ -651,7 +840,8 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px
                         bool byModel = false;
                         if ((P.flags & kCfgModelsVisible) && !(hard && (bySphere || byBox))) {   // the shadow traces ignore renderModels (kernels.cu:304)
                             Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
-                            byModel = traceModels<true, STATS>(S, biased, sd, cull, true, P.meshMode, dummy, stk, cnt);
+                            if (WIDE) byModel = traceModelsWide<true, STATS>(S, biased, sd, cull, true, P.meshMode, dummy, stk, cnt);
+                            else byModel = traceModels<true, STATS>(S, biased, sd, cull, true, P.meshMode, dummy, stk, cnt);
                         }
                         if (hard) shadowed = bySphere || byBox || byModel;
                         else hitsCount += (bySphere ? 1 : 0) + (byBox ? 1 : 0) + (byModel ? 1 : 0);
@@ -717,11 +907,13 @@ constexpr int kWavesPerTile = kWavesPerTileSide * kWavesPerTileSide;
 // Bits 0,2,4 of v -> bits 0,1,2 (one coordinate of a Z-order index).
 RT_DEV uint32_t evenBits3(uint32_t v) { return (v & 1u) | ((v >> 1) & 2u) | ((v >> 2) & 4u); }
 
-template <bool STATS>
+// WIDE = false: one wave per 8x8 pixel block, one lane per pixel.  WIDE = true: the waves listed in fb.extraMap, each
+// rendering one pixel row of one of the frame's heaviest blocks with eight lanes per ray.
+template <bool STATS, bool WIDE>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3))) void renderKernel(DevScene S, FrameParams P, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
                                                     float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
                                                     unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
-                                                    uint32_t* __restrict__ tileCost) {
+                                                    uint32_t* __restrict__ tileCost, BlockFeedback fb) {
     const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
     const unsigned long long cyclesStart = tileCost ? __builtin_readcyclecounter() : 0ull;
     __shared__ uint32_t stackBase[kMaxOctreeDepth * kBlockThreads];
@@ -733,27 +925,46 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
 
     // Workgroup B runs on XCD B % 8 (round-robin dispatch).  XCD x takes the tiles at positions x, x + 8, x + 16, ... of the
     // tile sequence: the 64 waves of a tile share one L2, and every XCD gets the same mix of cheap and expensive tiles.
-    uint32_t localTile, inTile;
-    if (P.blockOrder == 2) {
-        const uint32_t xcd = blockIdx.x % 8u, i = blockIdx.x / 8u;
-        localTile = (i / kWavesPerTile) * 8u + xcd;
-        inTile = i % kWavesPerTile;
-        if (localTile >= (uint32_t)P.ownedTiles) {
-            if (STATS && waveClocks && lane == 0) {
-                for (int k = 0; k < kWaveRecordWords; k++) waveClocks[kWaveRecordWords * (size_t)blockIdx.x + k] = 0;
-            }
-            return;
-        }
+    uint32_t localTile, inTile, sub = 0;
+    bool retire = false;
+    if (WIDE) {
+        const uint32_t e = fb.extraMap[blockIdx.x];
+        if (e != kNoExtraWave) {
+            const uint32_t blk = e & 0xFFFFFu;
+            sub = (e >> 20) & 7u;
+            localTile = blk / (uint32_t)kWavesPerTile; inTile = blk % (uint32_t)kWavesPerTile;
+        } else { localTile = 0; inTile = 0; retire = true; }
     } else {
-        localTile = blockIdx.x / kWavesPerTile; inTile = blockIdx.x % kWavesPerTile;
+        const uint32_t b = blockIdx.x;
+        if (P.blockOrder == 2) {
+            const uint32_t xcd = b % 8u, i = b / 8u;
+            localTile = (i / kWavesPerTile) * 8u + xcd;
+            inTile = i % kWavesPerTile;
+            if (localTile >= (uint32_t)P.ownedTiles) retire = true;
+        } else {
+            localTile = b / kWavesPerTile; inTile = b % kWavesPerTile;
+        }
+        // Expensive tiles first: the slowest waves of a frame run several hundred times longer than the median, so they
+        // must not be the last to start.  tileOrder lists this rank's tiles by the cost measured on the previous frame.
+        if (!retire && tileOrder) localTile = tileOrder[localTile];
+        if (!retire && P.split) {
+            const uint32_t blk = localTile * (uint32_t)kWavesPerTile + inTile;
+            if ((fb.heavyBits[blk >> 5] >> (blk & 31u)) & 1u) retire = true;      // split waves render this block
+        }
     }
-    // Expensive tiles first: the slowest waves of a frame run several hundred times longer than the median, so they
-    // must not be the last to start.  tileOrder lists this rank's tiles by the cost measured on the previous frame.
-    if (tileOrder) localTile = tileOrder[localTile];
+    if (retire) {
+        if (STATS && waveClocks && lane == 0) {
+            for (int k = 0; k < kWaveRecordWords; k++) waveClocks[kWaveRecordWords * (size_t)blockIdx.x + k] = 0;
+        }
+        return;
+    }
+    constexpr bool splitWave = WIDE;
     const uint32_t tile = localTile * (uint32_t)P.world + (uint32_t)P.rank;
     const uint32_t tileX = tile % (uint32_t)P.tilesX, tileY = tile / (uint32_t)P.tilesX;
-    // the waves of a tile walk it in Z order (neighbours in time are neighbours on screen); lane l is pixel (l & 7, l >> 3)
-    const uint32_t lx = evenBits3(inTile) * 8u + (lane & 7u), ly = evenBits3(inTile >> 1) * 8u + (lane >> 3);
+    // the waves of a tile walk it in Z order (neighbours in time are neighbours on screen).  A regular wave renders the whole
+    // 8x8 block, lane l = pixel (l & 7, l >> 3); a split wave renders row `sub` of the block with eight lanes per pixel.
+    const uint32_t bx = evenBits3(inTile) * 8u, by = evenBits3(inTile >> 1) * 8u;
+    const uint32_t lx = bx + (splitWave ? (lane >> 3) : (lane & 7u)), ly = by + (splitWave ? sub : (lane >> 3));
     const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
 
     Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0;
@@ -772,27 +983,30 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
             const float offX = antiAlias ? ((sIdx & 2) ? 0.75f : 0.25f) : 0.5f, offY = antiAlias ? ((sIdx & 1) ? 0.75f : 0.25f) : 0.5f;
             V3 p = rasterToCameraSpace(P, (float)x + offX, (float)y + offY);
             Closest ph;
-            V3 c = castSample<STATS>(S, P, camPos, normalise(p), x, y, stk, cnt, ph);
+            V3 c = castSample<STATS, WIDE>(S, P, camPos, normalise(p), x, y, stk, cnt, ph);
             if (sIdx == 0) primary = ph;
             total = antiAlias ? total + c : c;
         }
         col = antiAlias ? total / 4.0f : total;
-        size_t pix;
-        if (P.compactOutput) pix = (size_t)localTile * (RT_TILE_PX * RT_TILE_PX) + (size_t)ly * RT_TILE_PX + lx;
-        else pix = (size_t)y * (size_t)P.width + (size_t)x;
-        out[pix * 3 + 0] = packChannel(col.x);
-        out[pix * 3 + 1] = packChannel(col.y);
-        out[pix * 3 + 2] = packChannel(col.z);
-        if (ids) {
-            size_t fp = (size_t)y * (size_t)P.width + (size_t)x;
-            bool hit = primary.kind != KIND_NONE;
-            ids[fp * 2 + 0] = hit ? ((primary.kind << 24) | (primary.idx & 0xFFFFFF)) : -1;
-            ids[fp * 2 + 1] = hit ? primary.tri : -1;
-            if (tbuf) tbuf[fp] = primary.t;
-        } else if (tbuf) {
-            tbuf[(size_t)y * (size_t)P.width + (size_t)x] = primary.t;
+        if (!splitWave || (lane & 7u) == 0u) {      // the eight lanes of a split wave's pixel hold the same result
+            size_t pix;
+            if (P.compactOutput) pix = (size_t)localTile * (RT_TILE_PX * RT_TILE_PX) + (size_t)ly * RT_TILE_PX + lx;
+            else pix = (size_t)y * (size_t)P.width + (size_t)x;
+            out[pix * 3 + 0] = packChannel(col.x);
+            out[pix * 3 + 1] = packChannel(col.y);
+            out[pix * 3 + 2] = packChannel(col.z);
+            if (ids) {
+                size_t fp = (size_t)y * (size_t)P.width + (size_t)x;
+                bool hit = primary.kind != KIND_NONE;
+                ids[fp * 2 + 0] = hit ? ((primary.kind << 24) | (primary.idx & 0xFFFFFF)) : -1;
+                ids[fp * 2 + 1] = hit ? primary.tri : -1;
+                if (tbuf) tbuf[fp] = primary.t;
+            } else if (tbuf) {
+                tbuf[(size_t)y * (size_t)P.width + (size_t)x] = primary.t;
+            }
         }
     }
+    if (splitWave && (lane & 7u) != 0u) { cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; }
 
     if (STATS && waveClocks && lane == 0) {      // diagnostic: when this wave started and finished, and its section sums
         unsigned long long* rec = waveClocks + kWaveRecordWords * (size_t)blockIdx.x;
@@ -802,7 +1016,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     }
     if (tileCost && lane == 0) {
         const unsigned long long spent = __builtin_readcyclecounter() - cyclesStart;
-        atomicMax(&tileCost[localTile], (uint32_t)(spent >> 6) + 1u);   // a tile is as urgent as its slowest wave
+        // a split wave stands for the whole block: count it as what one regular wave would have needed, roughly
+        const uint32_t cost = ((uint32_t)(spent >> 6) + 1u) * (splitWave ? kSplitSpeedup : 1u);
+        atomicMax(&tileCost[localTile], cost);   // a tile is as urgent as its slowest wave
+        if (fb.blockCost) atomicMax(&fb.blockCost[localTile * (uint32_t)kWavesPerTile + inTile], cost);
     }
     // one atomic per wave and counter
     if (counters) {
@@ -866,12 +1083,101 @@ unsigned launchGridBlocks(const FrameParams& P) {
 
 hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
                         unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
-                        const uint32_t* tileOrder, uint32_t* tileCost) {
+                        const uint32_t* tileOrder, uint32_t* tileCost, BlockFeedback fb) {
     if (P.ownedTiles <= 0) return hipSuccess;
     dim3 grid(launchGridBlocks(P)), block(kBlockThreads);
-    if (stats) hipLaunchKernelGGL(renderKernel<true>, grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost);
-    else hipLaunchKernelGGL(renderKernel<false>, grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost);
+    if (stats) hipLaunchKernelGGL((renderKernel<true, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
+    else hipLaunchKernelGGL((renderKernel<false, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
     return hipGetLastError();
+}
+
+hipError_t launchRenderWide(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
+                            unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
+                            uint32_t* tileCost, BlockFeedback fb) {
+    if (P.ownedTiles <= 0 || !P.split) return hipSuccess;
+    dim3 grid((unsigned)kMaxExtraWaves), block(kBlockThreads);
+    if (stats) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
+    else hipLaunchKernelGGL((renderKernel<false, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
+    return hipGetLastError();
+}
+
+// One workgroup.  Chooses the time T every block should stay under in the next frame, and hands the blocks above it to
+// split waves (eight per block, one per pixel row, eight lanes per ray).
+// Model: a split block finishes kSplitSpeedup times sooner and its eight waves occupy wave slots for 8 / kSplitSpeedup times
+// the block's cost; the frame takes max(T, maxCost / kSplitSpeedup, (sum of costs + extra occupancy) / slots).  T is the
+// best of the candidates maxCost / 2^(k/2), k = 0..6, but at least floorCost; ratio256 / 256 scales the weight of the
+// extra occupancy.  Writes extraMap and heavyBits for the next frame and clears the costs.
+__global__ __launch_bounds__(1024) void selectHeavyKernel(uint32_t* __restrict__ blockCost, uint32_t* __restrict__ extraMap,
+                                                         uint32_t* __restrict__ heavyBits, uint32_t blocks, uint32_t slots, uint32_t ratio256,
+                                                         uint32_t floorCost) {
+    constexpr int kCandidates = 7;
+    __shared__ unsigned long long total, above[kCandidates];
+    __shared__ uint32_t used, maxCost, chosen;
+    if (threadIdx.x == 0) { total = 0; used = 0; maxCost = 0; }
+    if (threadIdx.x < kCandidates) above[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t m = 0;
+    unsigned long long sum = 0;
+    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) { const uint32_t c = blockCost[i]; sum += c; m = c > m ? c : m; }
+    atomicAdd(&total, sum);
+    atomicMax(&maxCost, m);
+    for (uint32_t i = threadIdx.x; i < (blocks + 31u) / 32u; i += blockDim.x) heavyBits[i] = 0u;
+    for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxExtraWaves; i += blockDim.x) extraMap[i] = kNoExtraWave;
+    __syncthreads();
+    uint32_t cand[kCandidates];
+    for (int k = 0; k < kCandidates; k++) {
+        const uint32_t half = maxCost >> (k / 2);
+        cand[k] = (k & 1) ? (uint32_t)(((unsigned long long)half * 181u) >> 8) : half;      // 181 / 256 = 1 / sqrt(2)
+        if (cand[k] < floorCost) cand[k] = floorCost;
+    }
+    unsigned long long mine[kCandidates] = {0, 0, 0, 0, 0, 0, 0};
+    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) {
+        const uint32_t c = blockCost[i];
+        for (int k = 0; k < kCandidates; k++) if (c > cand[k]) mine[k] += c;
+    }
+    for (int k = 0; k < kCandidates; k++) if (mine[k]) atomicAdd(&above[k], mine[k]);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long bestTime = ~0ull;
+        uint32_t bestT = maxCost;
+        for (int k = 0; k < kCandidates; k++) {
+            // occupancy added by splitting everything above the candidate: (8 / speedup - 1) x their cost
+            const unsigned long long extra = above[k] * (8u - kSplitSpeedup) / kSplitSpeedup;
+            const unsigned long long bulk = (total + ((extra * ratio256) >> 8)) / (slots ? slots : 1u);
+            unsigned long long time = k == 0 ? maxCost : (maxCost / kSplitSpeedup > cand[k] ? maxCost / kSplitSpeedup : cand[k]);
+            if (bulk > time) time = bulk;
+            if (time < bestTime) { bestTime = time; bestT = cand[k]; }
+        }
+        chosen = bestT;
+    }
+    __syncthreads();
+    const uint32_t limit = ratio256 ? chosen : 0u;      // ratio 0: split whatever fits (test mode)
+    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) {
+        const uint32_t c = blockCost[i];
+        blockCost[i] = 0u;
+        if (c <= limit) continue;
+        const uint32_t at = atomicAdd(&used, 8u);
+        if (at + 8u <= (uint32_t)kMaxExtraWaves) {
+            for (uint32_t s = 0; s < 8u; s++) extraMap[at + s] = i | (s << 20);
+            atomicOr(&heavyBits[i >> 5], 1u << (i & 31u));
+        }
+    }
+}
+
+hipError_t launchSelectHeavy(uint32_t* blockCost, uint32_t* extraMap, uint32_t* heavyBits, int blocks, int slots, int ratio256, uint32_t floorCost,
+                             hipStream_t stream) {
+    if (blocks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(selectHeavyKernel, dim3(1), dim3(1024), 0, stream, blockCost, extraMap, heavyBits, (uint32_t)blocks, (uint32_t)slots,
+                       (uint32_t)ratio256, floorCost);
+    return hipGetLastError();
+}
+
+int residentRenderWaves() {
+    int device = 0, cus = 0, perCu = 0;
+    if (hipGetDevice(&device) != hipSuccess) return 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<false, false>, kBlockThreads, 0) != hipSuccess) return 0;
+    return cus * perCu;
 }
 
 hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, uint32_t* clearNext, int n, hipStream_t stream) {
