@@ -1104,9 +1104,12 @@ hipError_t launchRenderWide(const DevScene& S, const FrameParams& P, uint8_t* ou
 // One workgroup.  Chooses the time T every block should stay under in the next frame, and hands the blocks above it to
 // split waves (eight per block, one per pixel row, eight lanes per ray).
 // Model: a split block finishes kSplitSpeedup times sooner and its eight waves occupy wave slots for 8 / kSplitSpeedup times
-// the block's cost; the frame takes max(T, maxCost / kSplitSpeedup, (sum of costs + extra occupancy) / slots).  T is the
-// best of the candidates maxCost / 2^(k/2), k = 0..6, but at least floorCost; ratio256 / 256 scales the weight of the
-// extra occupancy.  Writes extraMap and heavyBits for the next frame and clears the costs.
+// the block's cost (measured: 2.7 times sooner); the frame takes max(T, maxCost / kSplitSpeedup, 1.25 x (sum of costs +
+// extra occupancy) / slots) - the 1.25 is how far a real frame stays behind perfectly even packing.  T is the best of the
+// candidates maxCost / 2^(k/2), k = 0..6, but at least floorCost, and nothing is split unless that promises a frame at
+// least 10 % shorter; ratio256 / 256 scales the weight of the extra occupancy.  In practice a GPU that renders a whole
+// 1080p frame is limited by the sum of the work and splits nothing, while a rank that renders 1/8 of the tiles is limited
+// by its heaviest block and splits a few hundred.  Writes extraMap and heavyBits for the next frame and clears the costs.
 __global__ __launch_bounds__(1024) void selectHeavyKernel(uint32_t* __restrict__ blockCost, uint32_t* __restrict__ extraMap,
                                                          uint32_t* __restrict__ heavyBits, uint32_t blocks, uint32_t slots, uint32_t ratio256,
                                                          uint32_t floorCost) {
@@ -1138,15 +1141,17 @@ __global__ __launch_bounds__(1024) void selectHeavyKernel(uint32_t* __restrict__
     for (int k = 0; k < kCandidates; k++) if (mine[k]) atomicAdd(&above[k], mine[k]);
     __syncthreads();
     if (threadIdx.x == 0) {
-        unsigned long long bestTime = ~0ull;
+        unsigned long long bestTime = ~0ull, unsplitTime = 0;
         uint32_t bestT = maxCost;
         for (int k = 0; k < kCandidates; k++) {
             // occupancy added by splitting everything above the candidate: (8 / speedup - 1) x their cost
             const unsigned long long extra = above[k] * (8u - kSplitSpeedup) / kSplitSpeedup;
-            const unsigned long long bulk = (total + ((extra * ratio256) >> 8)) / (slots ? slots : 1u);
+            const unsigned long long bulk = (total + (k == 0 ? 0ull : (extra * ratio256) >> 8)) * 5u / 4u / (slots ? slots : 1u);
             unsigned long long time = k == 0 ? maxCost : (maxCost / kSplitSpeedup > cand[k] ? maxCost / kSplitSpeedup : cand[k]);
             if (bulk > time) time = bulk;
-            if (time < bestTime) { bestTime = time; bestT = cand[k]; }
+            if (k == 0) { bestTime = time; bestT = maxCost; }
+            else if (time < bestTime && time * 11u < (unsigned long long)unsplitTime * 10u) { bestTime = time; bestT = cand[k]; }
+            if (k == 0) unsplitTime = time;
         }
         chosen = bestT;
     }
