@@ -77,13 +77,19 @@ struct rt_ctx {
     // Block feedback (see rt::BlockFeedback): the heaviest 8x8 blocks of a frame are rendered by `split` waves in the next one.
     uint32_t* dBlockCost = nullptr;   // kMaxSplitBlocks
     uint32_t* dExtraMap = nullptr;    // kMaxExtraWaves
-    uint32_t* dHeavyBits = nullptr;   // kMaxSplitBlocks / 32
+    uint32_t* dHeavyBits = nullptr;   // kMaxSplitBlocks / 32 + 8
+    rt::SplitState* dSplitState = nullptr;
+    int splitSlot = 0;                // slot of dSplitState the next selection writes
     int split = 1;                    // 0 disables splitting
     int splitRatio256 = 256;          // a block is split if it costs more than this share (in 1/256) of the evenly spread frame time
     uint32_t splitFloor = 1500;       // ... and at least this much (wave cycles / 64)
     int residentWaves = 0;
     hipStream_t wideStream = nullptr;  // the split waves run beside the regular ones
     hipEvent_t evFork = nullptr, evJoin = nullptr;
+    // Host-mapped word the selection kernel writes the number of split waves to.  Read without synchronising: a stale value
+    // only decides whether a frame uses split waves at all (with split = 0 the regular waves render every block).
+    volatile uint32_t* hSplitWaves = nullptr;
+    uint32_t* dSplitWaves = nullptr;
     bool forceDeviceBuild = false;   // RT_DEVICE_BUILD=1: build every scene's octrees on the GPU
     // what rt_validate_scene_device needs besides the device arrays
     std::vector<uint32_t> mdlInfoHost;
@@ -150,7 +156,7 @@ rt::FrameParams launchParams(const rt_ctx* ctx, const DispatchPlan& plan, bool* 
     rt::FrameParams launch = plan.p;
     const int blocks = plan.p.ownedTiles * (RT_TILE / 8) * (RT_TILE / 8);
     const bool feedback = plan.ordered && ctx->split > 0 && blocks <= rt::kMaxSplitBlocks;
-    launch.split = (feedback && plan.haveOrder) ? 1 : 0;
+    launch.split = (feedback && plan.haveOrder && ctx->hSplitWaves && *ctx->hSplitWaves != 0u) ? 1 : 0;
     if (feedbackOut) *feedbackOut = feedback;
     return launch;
 }
@@ -170,13 +176,19 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
     const rt::FrameParams launch = launchParams(ctx, plan, &feedback);
     if (!plan.haveOrder) {
         RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2, stream));
-        if (feedback) RT_HIP(hipMemsetAsync(ctx->dBlockCost, 0, sizeof(uint32_t) * (size_t)blocks, stream));
+        if (feedback) {
+            RT_HIP(hipMemsetAsync(ctx->dBlockCost, 0, sizeof(uint32_t) * (size_t)blocks, stream));
+            RT_HIP(hipMemsetAsync(ctx->dSplitState, 0, sizeof(rt::SplitState), stream));
+        }
     }
     uint32_t* cur = ctx->dTileCost + (size_t)ctx->costSlot * kMaxOrderedTiles;
     uint32_t* nxt = ctx->dTileCost + (size_t)(ctx->costSlot ^ 1) * kMaxOrderedTiles;
-    rt::BlockFeedback fb{nullptr, nullptr, nullptr};
+    rt::BlockFeedback fb{nullptr, nullptr, nullptr, nullptr, nullptr};
     if (feedback) {
         fb.blockCost = ctx->dBlockCost;
+        // the selection after the previous frame wrote slot splitSlot ^ 1
+        fb.extraCount = &ctx->dSplitState->used[ctx->splitSlot ^ 1];
+        fb.hint = ctx->dSplitWaves;
         if (launch.split) { fb.extraMap = ctx->dExtraMap; fb.heavyBits = ctx->dHeavyBits; }
     }
     if (launch.split) {
@@ -191,7 +203,11 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
                             plan.haveOrder ? ctx->dTileOrder : nullptr, cur, fb));
     if (launch.split) RT_HIP(hipStreamWaitEvent(stream, ctx->evJoin, 0));
     RT_HIP(rt::launchRankTiles(cur, ctx->dTileOrder, nxt, p.ownedTiles, stream));
-    if (feedback) RT_HIP(rt::launchSelectHeavy(ctx->dBlockCost, ctx->dExtraMap, ctx->dHeavyBits, blocks, ctx->residentWaves, ctx->splitRatio256, ctx->splitFloor, stream));
+    if (feedback) {
+        RT_HIP(rt::launchSelectHeavy(ctx->dBlockCost, ctx->dExtraMap, ctx->dHeavyBits, blocks, ctx->dSplitState, ctx->splitSlot, ctx->residentWaves,
+                                     ctx->splitRatio256, ctx->splitFloor, stream));
+        ctx->splitSlot ^= 1;
+    }
     ctx->costSlot ^= 1;
     ctx->orderKey = plan.key;
     return RT_OK;
@@ -240,6 +256,7 @@ int renderToHost(rt_ctx* ctx, int width, int height, uint8_t* rgbOut, int32_t* i
         stats->tri_tests = counters[rt::kCntTriTests];
         stats->attr_fetches = counters[rt::kCntAttrFetches];
         stats->gate_tests = counters[rt::kCntGateTests];
+        stats->split_waves = ctx->hSplitWaves ? *ctx->hSplitWaves : 0u;
     }
     return RT_OK;
 }
@@ -275,6 +292,15 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
         if (se == hipSuccess) se = hipStreamCreateWithPriority(&c->wideStream, hipStreamNonBlocking, greatestPriority);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming);
+        void* hp = nullptr;
+        if (se == hipSuccess && !std::getenv("RT_NO_HINT")) se = hipHostMalloc(&hp, 64, hipHostMallocMapped);
+        if (se == hipSuccess && hp) {
+            c->hSplitWaves = static_cast<volatile uint32_t*>(hp);
+            *c->hSplitWaves = 0u;
+            void* dp = nullptr;
+            se = hipHostGetDevicePointer(&dp, hp, 0);
+            c->dSplitWaves = static_cast<uint32_t*>(dp);
+        }
         if (se != hipSuccess) { const int rc = failHip(se, "stream for split waves"); rt_destroy(c); return rc; }
     }
     if (const char* e = std::getenv("RT_SPLIT_FLOOR")) { const int v = std::atoi(e); if (v >= 0) c->splitFloor = (uint32_t)v; }
@@ -288,7 +314,8 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles); if (e == hipSuccess) c->dTileOrder = static_cast<uint32_t*>(q); }
     if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * rt::kMaxSplitBlocks); if (e == hipSuccess) c->dBlockCost = static_cast<uint32_t*>(q); }
     if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * rt::kMaxExtraWaves); if (e == hipSuccess) c->dExtraMap = static_cast<uint32_t*>(q); }
-    if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * (rt::kMaxSplitBlocks / 32)); if (e == hipSuccess) c->dHeavyBits = static_cast<uint32_t*>(q); }
+    if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * (rt::kMaxSplitBlocks / 32 + 8)); if (e == hipSuccess) c->dHeavyBits = static_cast<uint32_t*>(q); }
+    if (e == hipSuccess) { e = hipMalloc(&q, sizeof(rt::SplitState)); if (e == hipSuccess) { c->dSplitState = static_cast<rt::SplitState*>(q); e = hipMemset(q, 0, sizeof(rt::SplitState)); } }
     if (e != hipSuccess) { rt_destroy(c); return failHip(e, "hipMalloc(tile order)"); }
     e = hipEventCreate(&c->evStart);
     if (e == hipSuccess) e = hipEventCreate(&c->evStop);
@@ -311,9 +338,11 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->dBlockCost) (void)hipFree(ctx->dBlockCost);
     if (ctx->dExtraMap) (void)hipFree(ctx->dExtraMap);
     if (ctx->dHeavyBits) (void)hipFree(ctx->dHeavyBits);
+    if (ctx->dSplitState) (void)hipFree(ctx->dSplitState);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
     if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
     if (ctx->wideStream) (void)hipStreamDestroy(ctx->wideStream);
+    if (ctx->hSplitWaves) (void)hipHostFree(const_cast<uint32_t*>(ctx->hSplitWaves));
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     delete ctx;
@@ -476,15 +505,16 @@ int rt_profile_waves(rt_ctx* ctx, int width, int height, uint64_t* clocks_out, s
     if (!clocks_out || !waves_out) return fail(RT_ERR_INVALID, "null argument");
     RT_HIP(hipSetDevice(ctx->device));
     rt::FrameParams p = frameFor(ctx, width, height, 0, 1, false);
-    const rt::FrameParams planned = launchParams(ctx, planDispatch(ctx, p));
-    const size_t waves = (size_t)rt::launchGridBlocks(planned) + (planned.split ? (size_t)rt::kMaxExtraWaves : 0);
+    // regular waves first, then room for the split waves whether or not this frame ends up using them
+    const size_t waves = (size_t)rt::launchGridBlocks(p) + (size_t)rt::kMaxExtraWaves;
     *waves_out = waves;
     if (capacity_pairs < waves) return fail(RT_ERR_CAPACITY, "clock buffer too small");
     rc = ensureCapacity(&ctx->dFrame, &ctx->frameCap, (size_t)width * (size_t)height * 3);
     if (rc) return rc;
     void* d = nullptr;
     RT_HIP(hipMalloc(&d, waves * RT_WAVE_RECORD_WORDS * sizeof(uint64_t)));
-    hipError_t e = hipSuccess;
+    hipError_t e = hipMemset(d, 0, waves * RT_WAVE_RECORD_WORDS * sizeof(uint64_t));
+    if (e != hipSuccess) { (void)hipFree(d); return failHip(e, "rt_profile_waves"); }
     rc = launchOrdered(ctx, p, ctx->dFrame, nullptr, nullptr, nullptr, true, nullptr, static_cast<unsigned long long*>(d));
     if (rc) { (void)hipFree(d); return rc; }
     if (e == hipSuccess) e = hipMemcpy(clocks_out, d, waves * RT_WAVE_RECORD_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost);

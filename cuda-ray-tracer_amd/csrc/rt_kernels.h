@@ -13,7 +13,7 @@ namespace rt {
 // compact tile buffer (P.compactOutput).  ids / tbuf / counters may be null.  stats selects the instrumented kernel.
 hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
                         unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks = nullptr,
-                        const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr, BlockFeedback fb = BlockFeedback{nullptr, nullptr, nullptr});
+                        const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr, BlockFeedback fb = BlockFeedback{nullptr, nullptr, nullptr, nullptr, nullptr});
 
 // The split waves of the frame's heaviest blocks (fb.extraMap), kMaxExtraWaves workgroups; meant to run concurrently with
 // launchRender of the same frame on another stream.  waveClocks, if given, receives kMaxExtraWaves records.
@@ -21,11 +21,11 @@ hipError_t launchRenderWide(const DevScene& S, const FrameParams& P, uint8_t* ou
                             unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
                             uint32_t* tileCost, BlockFeedback fb);
 
-// Block feedback between frames (see BlockFeedback): chooses the blocks the next frame renders with split waves and
-// clears blockCost.  slots = waves resident on the device at once (residentRenderWaves()); a block is split if it costs
-// more than ratio256 / 256 of the frame's evenly spread time, and at least floorCost.
-hipError_t launchSelectHeavy(uint32_t* blockCost, uint32_t* extraMap, uint32_t* heavyBits, int blocks, int slots, int ratio256, uint32_t floorCost,
-                             hipStream_t stream);
+// Block feedback between frames (see BlockFeedback): gathers the statistics of the costs in blockCost into slot `slot` of
+// `state`, chooses the blocks the next frame renders with split waves (extraMap, heavyBits, state->used[slot]) and clears
+// blockCost.  slots = waves resident on the device at once (residentRenderWaves()).  heavyBits needs blocks / 32 + 8 words.
+hipError_t launchSelectHeavy(uint32_t* blockCost, uint32_t* extraMap, uint32_t* heavyBits, int blocks, SplitState* state, int slot, int slots,
+                             int ratio256, uint32_t floorCost, hipStream_t stream);
 int residentRenderWaves();
 
 // order = this rank's tiles sorted by descending cost (ties by index); clearNext[0..n) is zeroed for a later frame.

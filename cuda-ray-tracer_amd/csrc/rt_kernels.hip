@@ -916,6 +916,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
                                                     uint32_t* __restrict__ tileCost, BlockFeedback fb) {
     const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
     const unsigned long long cyclesStart = tileCost ? __builtin_readcyclecounter() : 0ull;
+    if (!WIDE && fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
     __shared__ uint32_t stackBase[kMaxOctreeDepth * kBlockThreads];
     __shared__ uint32_t stackMask[kMaxOctreeDepth * kBlockThreads];
     __shared__ unsigned long long profile[16];  // section accumulators of the instrumented kernel: (cycles, executions) x 8
@@ -928,8 +929,9 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     uint32_t localTile, inTile, sub = 0;
     bool retire = false;
     if (WIDE) {
-        const uint32_t e = fb.extraMap[blockIdx.x];
-        if (e != kNoExtraWave) {
+        const uint32_t count = *fb.extraCount;
+        if (blockIdx.x < (count < (uint32_t)kMaxExtraWaves ? count : (uint32_t)kMaxExtraWaves)) {
+            const uint32_t e = fb.extraMap[blockIdx.x];
             const uint32_t blk = e & 0xFFFFFu;
             sub = (e >> 20) & 7u;
             localTile = blk / (uint32_t)kWavesPerTile; inTile = blk % (uint32_t)kWavesPerTile;
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
         // Expensive tiles first: the slowest waves of a frame run several hundred times longer than the median, so they
         // must not be the last to start.  tileOrder lists this rank's tiles by the cost measured on the previous frame.
         if (!retire && tileOrder) localTile = tileOrder[localTile];
-        if (!retire && P.split) {
+        if (!retire && P.split && *fb.extraCount != 0u) {
             const uint32_t blk = localTile * (uint32_t)kWavesPerTile + inTile;
             if ((fb.heavyBits[blk >> 5] >> (blk & 31u)) & 1u) retire = true;      // split waves render this block
         }
@@ -1016,8 +1018,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     }
     if (tileCost && lane == 0) {
         const unsigned long long spent = __builtin_readcyclecounter() - cyclesStart;
-        // a split wave stands for the whole block: count it as what one regular wave would have needed, roughly
-        const uint32_t cost = ((uint32_t)(spent >> 6) + 1u) * (splitWave ? kSplitSpeedup : 1u);
+        // a split wave stands for the whole block: count it as what one regular wave would have needed.  The factor is a
+        // little below the measured speed-up (2.7) so that a block never looks heavier split than it was unsplit, which
+        // would keep a frame that does not profit from splitting in the split state.
+        const uint32_t own = (uint32_t)(spent >> 6) + 1u;
+        const uint32_t cost = splitWave ? own * 5u / 2u : own;
         atomicMax(&tileCost[localTile], cost);   // a tile is as urgent as its slowest wave
         if (fb.blockCost) atomicMax(&fb.blockCost[localTile * (uint32_t)kWavesPerTile + inTile], cost);
     }
@@ -1101,79 +1106,105 @@ hipError_t launchRenderWide(const DevScene& S, const FrameParams& P, uint8_t* ou
     return hipGetLastError();
 }
 
-// One workgroup.  Chooses the time T every block should stay under in the next frame, and hands the blocks above it to
-// split waves (eight per block, one per pixel row, eight lanes per ray).
-// Model: a split block finishes kSplitSpeedup times sooner and its eight waves occupy wave slots for 8 / kSplitSpeedup times
-// the block's cost (measured: 2.7 times sooner); the frame takes max(T, maxCost / kSplitSpeedup, 1.25 x (sum of costs +
-// extra occupancy) / slots) - the 1.25 is how far a real frame stays behind perfectly even packing.  T is the best of the
-// candidates maxCost / 2^(k/2), k = 0..6, but at least floorCost, and nothing is split unless that promises a frame at
-// least 10 % shorter; ratio256 / 256 scales the weight of the extra occupancy.  In practice a GPU that renders a whole
-// 1080p frame is limited by the sum of the work and splits nothing, while a rank that renders 1/8 of the tiles is limited
-// by its heaviest block and splits a few hundred.  Writes extraMap and heavyBits for the next frame and clears the costs.
-__global__ __launch_bounds__(1024) void selectHeavyKernel(uint32_t* __restrict__ blockCost, uint32_t* __restrict__ extraMap,
-                                                         uint32_t* __restrict__ heavyBits, uint32_t blocks, uint32_t slots, uint32_t ratio256,
-                                                         uint32_t floorCost) {
-    constexpr int kCandidates = 7;
-    __shared__ unsigned long long total, above[kCandidates];
-    __shared__ uint32_t used, maxCost, chosen;
-    if (threadIdx.x == 0) { total = 0; used = 0; maxCost = 0; }
-    if (threadIdx.x < kCandidates) above[threadIdx.x] = 0;
+// Cost bin of a block: two bins per power of two, bin 2e + h holds costs in [(2 + h) << (e - 1), (3 + h) << (e - 1)).
+RT_DEV int costBin(uint32_t c) {
+    if (c < 2u) return (int)c;
+    const int e = 31 - __builtin_clz(c);
+    return 2 * e + (int)((c >> (e - 1)) & 1u);
+}
+
+// After a frame: sum, maximum and a coarse histogram (cost sums per bin) of the block costs, into slot `slot` of the state.
+__global__ __launch_bounds__(256) void blockStatsKernel(const uint32_t* __restrict__ blockCost, uint32_t blocks, SplitState* __restrict__ st, int slot) {
+    __shared__ unsigned long long bins[kCostBins];
+    if (threadIdx.x < kCostBins) bins[threadIdx.x] = 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) st->used[slot] = 0;      // the selection that follows counts into it
     __syncthreads();
-    uint32_t m = 0;
-    unsigned long long sum = 0;
-    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) { const uint32_t c = blockCost[i]; sum += c; m = c > m ? c : m; }
-    atomicAdd(&total, sum);
-    atomicMax(&maxCost, m);
-    for (uint32_t i = threadIdx.x; i < (blocks + 31u) / 32u; i += blockDim.x) heavyBits[i] = 0u;
-    for (uint32_t i = threadIdx.x; i < (uint32_t)kMaxExtraWaves; i += blockDim.x) extraMap[i] = kNoExtraWave;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t c = i < blocks ? blockCost[i] : 0u;
+    if (c) atomicAdd(&bins[costBin(c)], (unsigned long long)c);
+    uint32_t m = c;
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(m, off, 64); m = o > m ? o : m; }
+    if ((threadIdx.x & 63u) == 0u && m) atomicMax(&st->maxCost[slot], m);
     __syncthreads();
-    uint32_t cand[kCandidates];
-    for (int k = 0; k < kCandidates; k++) {
-        const uint32_t half = maxCost >> (k / 2);
-        cand[k] = (k & 1) ? (uint32_t)(((unsigned long long)half * 181u) >> 8) : half;      // 181 / 256 = 1 / sqrt(2)
-        if (cand[k] < floorCost) cand[k] = floorCost;
-    }
-    unsigned long long mine[kCandidates] = {0, 0, 0, 0, 0, 0, 0};
-    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) {
-        const uint32_t c = blockCost[i];
-        for (int k = 0; k < kCandidates; k++) if (c > cand[k]) mine[k] += c;
-    }
-    for (int k = 0; k < kCandidates; k++) if (mine[k]) atomicAdd(&above[k], mine[k]);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long bestTime = ~0ull, unsplitTime = 0;
-        uint32_t bestT = maxCost;
-        for (int k = 0; k < kCandidates; k++) {
-            // occupancy added by splitting everything above the candidate: (8 / speedup - 1) x their cost
-            const unsigned long long extra = above[k] * (8u - kSplitSpeedup) / kSplitSpeedup;
-            const unsigned long long bulk = (total + (k == 0 ? 0ull : (extra * ratio256) >> 8)) * 5u / 4u / (slots ? slots : 1u);
-            unsigned long long time = k == 0 ? maxCost : (maxCost / kSplitSpeedup > cand[k] ? maxCost / kSplitSpeedup : cand[k]);
-            if (bulk > time) time = bulk;
-            if (k == 0) { bestTime = time; bestT = maxCost; }
-            else if (time < bestTime && time * 11u < (unsigned long long)unsplitTime * 10u) { bestTime = time; bestT = cand[k]; }
-            if (k == 0) unsplitTime = time;
-        }
-        chosen = bestT;
-    }
-    __syncthreads();
-    const uint32_t limit = ratio256 ? chosen : 0u;      // ratio 0: split whatever fits (test mode)
-    for (uint32_t i = threadIdx.x; i < blocks; i += blockDim.x) {
-        const uint32_t c = blockCost[i];
-        blockCost[i] = 0u;
-        if (c <= limit) continue;
-        const uint32_t at = atomicAdd(&used, 8u);
-        if (at + 8u <= (uint32_t)kMaxExtraWaves) {
-            for (uint32_t s = 0; s < 8u; s++) extraMap[at + s] = i | (s << 20);
-            atomicOr(&heavyBits[i >> 5], 1u << (i & 31u));
-        }
+    if (threadIdx.x < kCostBins && bins[threadIdx.x]) {
+        atomicAdd(&st->binSum[slot][threadIdx.x], bins[threadIdx.x]);
+        atomicAdd(&st->total[slot], bins[threadIdx.x]);
     }
 }
 
-hipError_t launchSelectHeavy(uint32_t* blockCost, uint32_t* extraMap, uint32_t* heavyBits, int blocks, int slots, int ratio256, uint32_t floorCost,
-                             hipStream_t stream) {
+// Chooses the cost bin from which blocks are split in the next frame, and hands those blocks to split waves (eight per
+// block, one per pixel row, eight lanes per ray).  Every workgroup derives the same decision from the statistics.
+// Model: a split block finishes kSplitSpeedup times sooner and its eight waves occupy wave slots for 8 / kSplitSpeedup times
+// the block's cost (measured: 2.7 times sooner); the frame takes max(T, maxCost / kSplitSpeedup, 1.25 x (sum of costs +
+// extra occupancy) / slots) - the 1.25 is how far a real frame stays behind perfectly even packing.  T runs over the lower
+// edges of the top cost bins.  Nothing is split unless the model promises a frame at least 10 % shorter and the frame is
+// clearly limited by its heaviest block: that block alone must take more than 1.6 times the evenly packed frame to start
+// splitting, 1.3 times to carry on (the costs of split blocks are estimates; without the band a frame near the limit
+// would flip every other frame).  In practice a GPU that renders a whole 1080p frame is limited by the sum of the work
+// and splits nothing, while a rank that renders a fraction of the tiles is limited by its heaviest block and splits a
+// few hundred.  ratio256 / 256 scales the weight of the extra occupancy; 0 splits whatever fits (test mode).
+// Also clears the block costs and the other slot's statistics.
+__global__ __launch_bounds__(256) void selectHeavyKernel(uint32_t* __restrict__ blockCost, uint32_t* __restrict__ extraMap,
+                                                        uint32_t* __restrict__ heavyBits, uint32_t blocks, SplitState* __restrict__ st, int slot,
+                                                        uint32_t slots, uint32_t ratio256, uint32_t floorCost) {
+    __shared__ int chosenBin;
+    if (threadIdx.x == 0) {
+        const unsigned long long total = st->total[slot];
+        const uint32_t maxCost = st->maxCost[slot];
+        const bool wasSplit = st->used[slot ^ 1] != 0u;
+        const unsigned long long packed = total * 5u / 4u / (slots ? slots : 1u);
+        const bool allow = (unsigned long long)maxCost * 10u > packed * (wasSplit ? 13u : 16u);
+        const int top = costBin(maxCost);
+        int best = top + 1;                                   // nothing split
+        if (ratio256 == 0u) best = 0;
+        else if (allow && maxCost > 0u) {
+            const unsigned long long unsplitTime = maxCost > packed ? maxCost : packed;
+            unsigned long long bestTime = unsplitTime, above = 0;
+            for (int b = top; b >= 2 && b > top - 7; b--) {
+                above += st->binSum[slot][b];
+                const int e = b >> 1;
+                const unsigned long long edge = (unsigned long long)(2 + (b & 1)) << (e - 1);      // lower edge of bin b
+                const unsigned long long extra = above * (8u - kSplitSpeedup) / kSplitSpeedup;
+                const unsigned long long bulk = (total + ((extra * ratio256) >> 8)) * 5u / 4u / (slots ? slots : 1u);
+                unsigned long long time = maxCost / kSplitSpeedup > edge ? maxCost / kSplitSpeedup : edge;
+                if (bulk > time) time = bulk;
+                if (time < bestTime && time * 10u < unsplitTime * 9u) { bestTime = time; best = b; }
+            }
+        }
+        chosenBin = best;
+    }
+    if (blockIdx.x == 0) {      // the other slot's statistics are accumulated by the next frame
+        if (threadIdx.x < kCostBins) st->binSum[slot ^ 1][threadIdx.x] = 0;
+        if (threadIdx.x == 0) { st->total[slot ^ 1] = 0; st->maxCost[slot ^ 1] = 0; }
+    }
+    __syncthreads();
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    bool heavy = false;
+    if (i < blocks) {
+        const uint32_t c = blockCost[i];
+        blockCost[i] = 0u;
+        if (c > 0u && c >= floorCost && costBin(c) >= chosenBin) {
+            const uint32_t at = atomicAdd(&st->used[slot], 8u);
+            if (at + 8u <= (uint32_t)kMaxExtraWaves) {
+                for (uint32_t s = 0; s < 8u; s++) extraMap[at + s] = i | (s << 20);
+                heavy = true;
+            }
+        }
+    }
+    const unsigned long long mask = __ballot(heavy);
+    if ((threadIdx.x & 63u) == 0u) {
+        const uint32_t word = (blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+        heavyBits[word] = (uint32_t)mask; heavyBits[word + 1] = (uint32_t)(mask >> 32);
+    }
+}
+
+hipError_t launchSelectHeavy(uint32_t* blockCost, uint32_t* extraMap, uint32_t* heavyBits, int blocks, SplitState* state, int slot, int slots,
+                             int ratio256, uint32_t floorCost, hipStream_t stream) {
     if (blocks <= 0) return hipSuccess;
-    hipLaunchKernelGGL(selectHeavyKernel, dim3(1), dim3(1024), 0, stream, blockCost, extraMap, heavyBits, (uint32_t)blocks, (uint32_t)slots,
-                       (uint32_t)ratio256, floorCost);
+    const unsigned groups = (unsigned)((blocks + 255) / 256);
+    hipLaunchKernelGGL(blockStatsKernel, dim3(groups), dim3(256), 0, stream, blockCost, (uint32_t)blocks, state, slot);
+    hipLaunchKernelGGL(selectHeavyKernel, dim3(groups), dim3(256), 0, stream, blockCost, extraMap, heavyBits, (uint32_t)blocks, state, slot,
+                       (uint32_t)slots, (uint32_t)ratio256, floorCost);
     return hipGetLastError();
 }
 

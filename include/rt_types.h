@@ -183,6 +183,7 @@ typedef struct rt_frame_stats {
     uint64_t tri_tests;       /* ray/triangle tests (stats launches only) */
     uint64_t attr_fetches;    /* closest-hit vertex attribute fetches (stats launches only) */
     uint64_t gate_tests;      /* whole-model bounding-box gate tests (stats launches only) */
+    uint64_t split_waves;     /* extra waves the most recent block selection chose for the frame after it (0 = nothing split) */
 } rt_frame_stats;
 
 /* Sizes of the flattened device scene, for roofline accounting and tests. */
