@@ -80,6 +80,7 @@ struct rt_ctx {
     uint32_t* dHeavyBits = nullptr;   // kMaxSplitBlocks / 32 + 8
     rt::SplitState* dSplitState = nullptr;
     int splitSlot = 0;                // slot of dSplitState the next selection writes
+    int framesSinceSelection = 0;     // while nothing is split the selection only runs every kIdleSelectionPeriod-th frame
     int split = 1;                    // 0 disables splitting
     int splitRatio256 = 256;          // a block is split if it costs more than this share (in 1/256) of the evenly spread frame time
     uint32_t splitFloor = 1500;       // ... and at least this much (wave cycles / 64)
@@ -105,6 +106,7 @@ void freeScene(rt_ctx* c) {
     c->haveScene = false;
 }
 
+constexpr int kIdleSelectionPeriod = 8;
 constexpr int kMaxOrderedTiles = 1 << 16;   // frames with more tiles per rank are rendered in plain tile order
 
 int tilesAlong(int pixels) { return (pixels + RT_TILE - 1) / RT_TILE; }
@@ -203,7 +205,13 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
                             plan.haveOrder ? ctx->dTileOrder : nullptr, cur, fb));
     if (launch.split) RT_HIP(hipStreamWaitEvent(stream, ctx->evJoin, 0));
     RT_HIP(rt::launchRankTiles(cur, ctx->dTileOrder, nxt, p.ownedTiles, stream));
-    if (feedback) {
+    // While the last selection split nothing (host hint, possibly a frame or two old), look again only now and then: the
+    // block costs keep accumulating their maxima in between, and a frame that does not split saves two small launches.
+    const bool idle = !launch.split && ctx->hSplitWaves && *ctx->hSplitWaves == 0u;
+    if (feedback && idle && ++ctx->framesSinceSelection < kIdleSelectionPeriod && plan.haveOrder) {
+        // nothing to do this frame
+    } else if (feedback) {
+        ctx->framesSinceSelection = 0;
         RT_HIP(rt::launchSelectHeavy(ctx->dBlockCost, ctx->dExtraMap, ctx->dHeavyBits, blocks, ctx->dSplitState, ctx->splitSlot, ctx->residentWaves,
                                      ctx->splitRatio256, ctx->splitFloor, stream));
         ctx->splitSlot ^= 1;
