@@ -83,6 +83,7 @@ struct rt_ctx {
     int framesSinceSelection = 0;     // while nothing is split the selection only runs every kIdleSelectionPeriod-th frame
     int split = 1;                    // 0 disables splitting
     int splitRatio256 = 256;          // a block is split if it costs more than this share (in 1/256) of the evenly spread frame time
+    int splitStartTenths = 16;        // splitting starts when the heaviest block exceeds this many tenths of the evenly packed frame
     uint32_t splitFloor = 1500;       // ... and at least this much (wave cycles / 64)
     int residentWaves = 0;
     hipStream_t wideStream = nullptr;  // the split waves run beside the regular ones
@@ -213,7 +214,7 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
     } else if (feedback) {
         ctx->framesSinceSelection = 0;
         RT_HIP(rt::launchSelectHeavy(ctx->dBlockCost, ctx->dExtraMap, ctx->dHeavyBits, blocks, ctx->dSplitState, ctx->splitSlot, ctx->residentWaves,
-                                     ctx->splitRatio256, ctx->splitFloor, stream));
+                                     ctx->splitRatio256, ctx->splitFloor, ctx->splitStartTenths, stream));
         ctx->splitSlot ^= 1;
     }
     ctx->costSlot ^= 1;
@@ -311,6 +312,7 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
         }
         if (se != hipSuccess) { const int rc = failHip(se, "stream for split waves"); rt_destroy(c); return rc; }
     }
+    if (const char* e = std::getenv("RT_SPLIT_START")) { const int v = std::atoi(e); if (v >= 4 && v <= 1000) c->splitStartTenths = v; }
     if (const char* e = std::getenv("RT_SPLIT_FLOOR")) { const int v = std::atoi(e); if (v >= 0) c->splitFloor = (uint32_t)v; }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, sizeof(unsigned long long) * rt::kCntCount);

@@ -25,7 +25,7 @@ hipError_t launchRenderWide(const DevScene& S, const FrameParams& P, uint8_t* ou
 // `state`, chooses the blocks the next frame renders with split waves (extraMap, heavyBits, state->used[slot]) and clears
 // blockCost.  slots = waves resident on the device at once (residentRenderWaves()).  heavyBits needs blocks / 32 + 8 words.
 hipError_t launchSelectHeavy(uint32_t* blockCost, uint32_t* extraMap, uint32_t* heavyBits, int blocks, SplitState* state, int slot, int slots,
-                             int ratio256, uint32_t floorCost, hipStream_t stream);
+                             int ratio256, uint32_t floorCost, int startTenths, hipStream_t stream);
 int residentRenderWaves();
 
 // order = this rank's tiles sorted by descending cost (ties by index); clearNext[0..n) is zeroed for a later frame.

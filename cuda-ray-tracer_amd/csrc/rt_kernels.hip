@@ -188,7 +188,7 @@ struct SectionTimer {
         if (STATS) {
             unsigned long long dt = __builtin_readcyclecounter() - t0;
             unsigned long long active = __ballot(1);
-            if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)active) - 1)) { stk.prof[2 * slot] += dt; stk.prof[2 * slot + 1] += 1; }
+            if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)active) - 1)) { stk.prof[2 * slot] += dt; stk.prof[2 * slot + 1] += 1ull + ((unsigned long long)__builtin_popcountll(active) << 32); }
         }
     }
 };
@@ -1146,14 +1146,14 @@ __global__ __launch_bounds__(256) void blockStatsKernel(const uint32_t* __restri
 // Also clears the block costs and the other slot's statistics.
 __global__ __launch_bounds__(256) void selectHeavyKernel(uint32_t* __restrict__ blockCost, uint32_t* __restrict__ extraMap,
                                                         uint32_t* __restrict__ heavyBits, uint32_t blocks, SplitState* __restrict__ st, int slot,
-                                                        uint32_t slots, uint32_t ratio256, uint32_t floorCost) {
+                                                        uint32_t slots, uint32_t ratio256, uint32_t floorCost, uint32_t startTenths) {
     __shared__ int chosenBin;
     if (threadIdx.x == 0) {
         const unsigned long long total = st->total[slot];
         const uint32_t maxCost = st->maxCost[slot];
         const bool wasSplit = st->used[slot ^ 1] != 0u;
         const unsigned long long packed = total * 5u / 4u / (slots ? slots : 1u);
-        const bool allow = (unsigned long long)maxCost * 10u > packed * (wasSplit ? 13u : 16u);
+        const bool allow = (unsigned long long)maxCost * 10u > packed * (wasSplit ? startTenths - 3u : startTenths);
         const int top = costBin(maxCost);
         int best = top + 1;                                   // nothing split
         if (ratio256 == 0u) best = 0;
@@ -1199,12 +1199,12 @@ __global__ __launch_bounds__(256) void selectHeavyKernel(uint32_t* __restrict__ 
 }
 
 hipError_t launchSelectHeavy(uint32_t* blockCost, uint32_t* extraMap, uint32_t* heavyBits, int blocks, SplitState* state, int slot, int slots,
-                             int ratio256, uint32_t floorCost, hipStream_t stream) {
+                             int ratio256, uint32_t floorCost, int startTenths, hipStream_t stream) {
     if (blocks <= 0) return hipSuccess;
     const unsigned groups = (unsigned)((blocks + 255) / 256);
     hipLaunchKernelGGL(blockStatsKernel, dim3(groups), dim3(256), 0, stream, blockCost, (uint32_t)blocks, state, slot);
     hipLaunchKernelGGL(selectHeavyKernel, dim3(groups), dim3(256), 0, stream, blockCost, extraMap, heavyBits, (uint32_t)blocks, state, slot,
-                       (uint32_t)slots, (uint32_t)ratio256, floorCost);
+                       (uint32_t)slots, (uint32_t)ratio256, floorCost, (uint32_t)startTenths);
     return hipGetLastError();
 }
 

@@ -118,7 +118,7 @@ int rt_count_rays(rt_ctx* ctx, int width, int height, rt_frame_stats* stats);
 /*
  * Diagnostic: renders one frame with the instrumented kernel and returns RT_WAVE_RECORD_WORDS 64-bit words per wave of
  * the launch: [0],[1] the 100 MHz wall-clock ticks at which it started and finished (0,0 for waves of padding
- * workgroups); then (shader cycles, executions) pairs for eight sections: octree node visits, triangle tests, the
+ * workgroups); then (shader cycles, executions + lanes active at those executions << 32) pairs for eight sections: octree node visits, triangle tests, the
  * up-front model gates, whole mesh traces, linear-table closest traces, surface + lighting, linear-table shadow tests,
  * unused.  Wave i is workgroup i of the launch.  capacity_pairs counts waves (records).  *waves_out receives the wave
  * count.  No reference counterpart.

@@ -33,7 +33,10 @@ for i in range(bins):
     a, b = edges[i], edges[i + 1]
     active = (np.minimum(e - t0, b) - np.maximum(s - t0, a)).clip(min=0).sum() / (b - a)
     print(f"  {a / 100:8.1f}-{b / 100:8.1f} us: {active:7.1f} waves resident on average")
-sec = clk[valid, 2:].astype(np.float64)
+raw = clk[valid, 2:]
+lanes = (raw[:, 1::2] >> np.uint64(32)).astype(np.float64)      # lanes active, summed over the executions of a section
+sec = raw.astype(np.float64)
+sec[:, 1::2] = (raw[:, 1::2] & np.uint64(0xffffffff)).astype(np.float64)
 tot_cycles = dur * 2400.0   # rough: 2.4 GHz
 print("share of wave time (all waves): node visits %.1f%%, triangle tests %.1f%%, model gates %.1f%%, whole mesh traces %.1f%%" % tuple(100 * sec[:, k].sum() / tot_cycles.sum() for k in (0, 2, 4, 6)))
 heavy = dur > np.percentile(dur, 99)
@@ -47,6 +50,8 @@ names = ["node visits", "triangle tests", "model gates", "whole mesh traces", "l
 for label, sel in (("all waves", np.ones(len(dur), bool)), ("heavy 1% waves", heavy)):
     print(label + ": " + ", ".join("%s %.1f%% (%.0f/wave, %.0f cyc each)" % (names[k], 100 * sec[sel, 2 * k].sum() / tot_cycles[sel].sum(), sec[sel, 2 * k + 1].mean(),
                                                                             sec[sel, 2 * k].sum() / max(sec[sel, 2 * k + 1].sum(), 1)) for k in range(7)))
+for label, sel in (("all waves", np.ones(len(dur), bool)), ("heavy 1% waves", heavy)):
+    print(label + ", lanes active per execution: " + ", ".join("%s %.1f" % (names[k], lanes[sel, k].sum() / max(sec[sel, 2 * k + 1].sum(), 1)) for k in range(7)))
 print("heavy 1%% waves: whole mesh traces %.1f%% of their time (%.0f calls/wave, %.0f cyc/call)" % (
     100 * sec[heavy, 6].sum() / tot_cycles[heavy].sum(), sec[heavy, 7].mean(), sec[heavy, 6].sum() / max(sec[heavy, 7].sum(), 1)))
 print("slowest waves (wave index, start us, dur us):", [(int(i), round(float((clk[i, 0] - t0) / 100.0), 1), round(float((clk[i, 1] - clk[i, 0]) / 100.0), 1)) for i in idx])
