@@ -273,7 +273,7 @@ hipError_t buildMeshesOnDevice(const rt_scene_desc& scene, const FlatScene& flat
     const int modelCount = (int)flat.deviceModels.size();
     const uint32_t total = (uint32_t)flat.triangleCount;
     if (modelCount == 0 || total == 0) return hipSuccess;
-    if (flat.triangleCount > (int64_t)0x7fffffff) { err = "too many triangles for the device builder"; return hipErrorInvalidValue; }
+    if (flat.triangleCount + kSpareTriangles > (int64_t)kMaxTriangleRecords) { err = "too many triangles for the device builder"; return hipErrorInvalidValue; }
     if (modelCount >= (1 << 24)) { err = "too many models for the device builder"; return hipErrorInvalidValue; }
     const uint32_t forestNodes = (uint32_t)(flat.nodes.size() / kNodeFloat4s);
     const uint32_t capacity = forestNodes + total;     // an internal node below a root has at least two children
@@ -371,15 +371,15 @@ hipError_t buildMeshesOnDevice(const rt_scene_desc& scene, const FlatScene& flat
     RT_TRY(hipMemcpy(host, counters, sizeof host, hipMemcpyDeviceToHost));
     if (host[kCtrBadNode]) { err = "device octree builder: node " + std::to_string(host[kCtrBadNode] - 1) + " has a child or leaf outside its range"; return hipErrorUnknown; }
 
-    // 5: final arrays (exact sizes; one spare triangle record, see rt_scene.cpp)
+    // 5: final arrays (exact sizes; spare triangle records at the end, see kSpareTriangles)
     void* p = nullptr;
     RT_TRY(hipMalloc(&p, (size_t)nodeCount * kNodeFloat4s * sizeof(F4)));
     out.nodes = static_cast<F4*>(p);
-    hipError_t e = hipMalloc(&p, ((size_t)total + 1) * 3 * sizeof(F4));
+    hipError_t e = hipMalloc(&p, ((size_t)total + kSpareTriangles) * 3 * sizeof(F4));
     if (e == hipSuccess) { out.tris = static_cast<F4*>(p); e = hipMalloc(&p, (size_t)total * kAttrFloat4s * sizeof(F4)); }
     if (e == hipSuccess) out.attrs = static_cast<F4*>(p);
     if (e == hipSuccess) e = hipMemcpy(out.nodes, nodes, (size_t)nodeCount * kNodeFloat4s * sizeof(F4), hipMemcpyDeviceToDevice);
-    if (e == hipSuccess) e = hipMemset(out.tris + 3 * (size_t)total, 0, 3 * sizeof(F4));
+    if (e == hipSuccess) e = hipMemset(out.tris + 3 * (size_t)total, 0, 3 * kSpareTriangles * sizeof(F4));
     if (e == hipSuccess) {
         hipLaunchKernelGGL(emitTrianglesKernel, dim3((total + 255) / 256), dim3(256), 0, nullptr, dModels, modelCount, total, valsOut, lastFlag, out.tris);
         hipLaunchKernelGGL(emitAttributesKernel, dim3((total + 255) / 256), dim3(256), 0, nullptr, dModels, modelCount, total, out.attrs);
@@ -394,7 +394,7 @@ hipError_t buildMeshesOnDevice(const rt_scene_desc& scene, const FlatScene& flat
     out.nodeCount = nodeCount;
     out.leafCount = host[kCtrLeaves];
     out.depth = (int)host[kCtrDepth];
-    out.triangleRecords = (int64_t)total + 1;
+    out.triangleRecords = (int64_t)total + kSpareTriangles;
     return hipSuccess;
 }
 

@@ -48,6 +48,10 @@ constexpr uint32_t kTriIdMask = (1u << kTriChunkShift) - 1u;
 // Attributes for shading, 7 float4 per triangle, indexed by triBase(model) + id:
 //   { n0.xyz, ka0.x } { n1.xyz, ka0.y } { n2.xyz, ka0.z } { ka1.xyz, kd0.x } { ka2.xyz, kd0.y } { kd1.xyz, kd0.z } { kd2.xyz, 0 }
 constexpr int kAttrFloat4s = 7;
+// The triangle array ends with this many zeroed records: a split wave reads eight consecutive records wherever a leaf starts.
+constexpr int kSpareTriangles = 8;
+// The traversal queues leaves as (first triangle record | chunk mask << 24).
+constexpr uint32_t kMaxTriangleRecords = 1u << 24;
 
 struct F4 { float x, y, z, w; };
 

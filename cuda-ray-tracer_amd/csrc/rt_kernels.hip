@@ -28,6 +28,8 @@ typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 #define RT_DEV __device__ __forceinline__
 constexpr int kBlockThreads = 64;   // render workgroups are single waves
 constexpr uint32_t kSplitSpeedup = 3; // a block rendered by eight split waves is taken to finish this many times sooner
+constexpr int kLeafQueue = 16;       // queued leaves per lane (a node visit can add eight)
+constexpr uint32_t kNoTriangle = 0xFFFFFFFFu;
 constexpr int kWaveRecordWords = 18; // per-wave diagnostic record: start, end, 8 x (cycles, executions)
 #define FAR_T 999.0f
 
@@ -175,6 +177,7 @@ struct Counters { uint32_t rays, nodeTests, triTests, attrFetches, gateTests; };
 struct StackRef {
     uint32_t* base;   // &stackBase[0][tid]
     uint32_t* mask;
+    uint32_t* leaves; // &leafQueue[0][tid]: leaves found but not yet intersected
     unsigned long long* prof;   // instrumented kernel only: 8 per-wave accumulators in LDS (see renderKernel)
 };
 
@@ -321,78 +324,89 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
     // children still to visit below the current node; the start state is one pseudo child that resolves to the forest root
     uint32_t base = S.forestRoot, imask = 0, hits = 1;
     int sp = 0;
-    uint32_t pend = 0;          // leaf children still to intersect (permuted order)
-    uint32_t lr0 = 0, lr1 = 0, lr2 = 0, lr3 = 0, lr4 = 0, lr5 = 0, lr6 = 0, lr7 = 0;
+    // Leaves are not intersected where they are found: a lane queues them (first triangle | chunk mask << 24) and keeps
+    // descending, and the wave turns to triangles when most of its lanes have some - one triangle per lane and turn, a
+    // lane whose leaf ends takes its next one at once.  With leaves intersected on the spot the triangle loop ran with 15
+    // of 64 lanes active on average (leaf lengths differ, and most lanes are descending at any moment).
+    uint32_t queued = 0, qhead = 0, cursor = kNoTriangle, cursorChunks = 0xffu;     // the queue is a ring of kLeafQueue entries
+    uint32_t* leafQ = stk.leaves;
     bool found = false;
 
     for (;;) {
-        // ---- descend until this lane has triangles to test or has nothing left to visit
-        while (pend == 0) {
-            SectionTimer<STATS> timerA;
-            if (hits == 0) {
-                if (sp == 0) break;
-                sp--;                       // siblings left on an upper level
-                base = stk.base[sp * kBlockThreads];
-                uint32_t packed = stk.mask[sp * kBlockThreads];
-                imask = packed & 0xffu;
-                hits = packed >> 8;
-            }
-            uint32_t k = __builtin_ctz(hits);
-            hits &= hits - 1;
-            uint32_t c = k ^ oct;
-            const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
-
-            // The whole 128-byte record is requested at once and nothing below branches before the box test, so a node
-            // visit costs one memory round trip (leaf references included, whether or not a leaf is hit).
-            const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
-            const u4_t head = *reinterpret_cast<const u4_t*>(np), meta = *reinterpret_cast<const u4_t*>(np + 1);
-            const u4_t ra = *reinterpret_cast<const u4_t*>(np + 5), rb = *reinterpret_cast<const u4_t*>(np + 6);
-            uint32_t hmask = testChildren(np, head, sr, tmin, ANYHIT ? FAR_T : best.t);
-            if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
-                const int mm = (int)meta.z;
-                bool enter = pregated ? (((gateBits >> mm) & 1ull) != 0) : gate(mm);
-                if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
-                    chunkMask = 0;
-                    for (int b = 0; b < 8; b++) {
-                        if (STATS) cnt.gateTests++;
-                        float tGate;
-                        if (boxHit(xyz(ld4(S.mdlChunkMin + 8 * mm + b)), xyz(ld4(S.mdlChunkMax + 8 * mm + b)), o, d, tGate)) chunkMask |= 1u << b;
-                    }
-                    enter = chunkMask != 0;
+        const bool moreNodes = hits != 0 || sp > 0;
+        const bool haveTriangles = queued != 0 || cursor != kNoTriangle;
+        if (!moreNodes && !haveTriangles) break;
+        const bool canDescend = moreNodes && queued <= (uint32_t)(kLeafQueue - 8);
+        const int wantNodes = __builtin_popcountll(__ballot(canDescend)), wantTriangles = __builtin_popcountll(__ballot(haveTriangles));
+        if (wantNodes != 0 && wantNodes >= wantTriangles) {
+            // ---- one node visit for every lane that can take one
+            if (canDescend) {
+                SectionTimer<STATS> timerA;
+                if (hits == 0) {
+                    sp--;                       // siblings left on an upper level
+                    base = stk.base[sp * kBlockThreads];
+                    uint32_t packed = stk.mask[sp * kBlockThreads];
+                    imask = packed & 0xffu;
+                    hits = packed >> 8;
                 }
-                if (!enter) hmask = 0;
-            }
-            uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
-            if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
-            if (hits != 0) {   // keep the siblings that are still waiting
-                stk.base[sp * kBlockThreads] = base;
-                stk.mask[sp * kBlockThreads] = imask | (hits << 8);
-                sp++;
-            }
-            base = meta.x;
-            imask = nodeImask;
-            hits = permuteOctants(hmask & nodeImask, oct);
-            pend = permuteOctants(hmask & nodeLmask, oct);
-            lr0 = ra.x; lr1 = ra.y; lr2 = ra.z; lr3 = ra.w; lr4 = rb.x; lr5 = rb.y; lr6 = rb.z; lr7 = rb.w;
-            timerA.stop(stk, 0);
-        }
-        if (pend == 0) break;   // nothing left
+                uint32_t k = __builtin_ctz(hits);
+                hits &= hits - 1;
+                uint32_t c = k ^ oct;
+                const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
 
-        // ---- intersect the triangles of the pending leaves
-        while (pend != 0) {
-            uint32_t k = __builtin_ctz(pend);
-            pend &= pend - 1;
-            uint32_t c = k ^ oct;
-            uint32_t start = c == 0 ? lr0 : c == 1 ? lr1 : c == 2 ? lr2 : c == 3 ? lr3 : c == 4 ? lr4 : c == 5 ? lr5 : c == 6 ? lr6 : lr7;
-            const F4* tp = S.tris + (size_t)start * 3;
-            // software pipeline: the next record is requested before the current one is intersected (the triangle array ends
-            // with one spare record, so reading one past the leaf is always in bounds)
-            f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
-            for (;;) {
+                // The whole 128-byte record is requested at once and nothing below branches before the box test, so a node
+                // visit costs one memory round trip (leaf references included, whether or not a leaf is hit).
+                const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
+                const u4_t head = *reinterpret_cast<const u4_t*>(np), meta = *reinterpret_cast<const u4_t*>(np + 1);
+                const u4_t ra = *reinterpret_cast<const u4_t*>(np + 5), rb = *reinterpret_cast<const u4_t*>(np + 6);
+                uint32_t hmask = testChildren(np, head, sr, tmin, ANYHIT ? FAR_T : best.t);
+                if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
+                    const int mm = (int)meta.z;
+                    bool enter = pregated ? (((gateBits >> mm) & 1ull) != 0) : gate(mm);
+                    if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
+                        chunkMask = 0;
+                        for (int b = 0; b < 8; b++) {
+                            if (STATS) cnt.gateTests++;
+                            float tGate;
+                            if (boxHit(xyz(ld4(S.mdlChunkMin + 8 * mm + b)), xyz(ld4(S.mdlChunkMax + 8 * mm + b)), o, d, tGate)) chunkMask |= 1u << b;
+                        }
+                        enter = chunkMask != 0;
+                    }
+                    if (!enter) hmask = 0;
+                }
+                uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
+                if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
+                if (hits != 0) {   // keep the siblings that are still waiting
+                    stk.base[sp * kBlockThreads] = base;
+                    stk.mask[sp * kBlockThreads] = imask | (hits << 8);
+                    sp++;
+                }
+                base = meta.x;
+                imask = nodeImask;
+                hits = permuteOctants(hmask & nodeImask, oct);
+                uint32_t pend = permuteOctants(hmask & nodeLmask, oct);
+                while (pend != 0) {             // queue the leaves front to back
+                    const uint32_t lc = (uint32_t)__builtin_ctz(pend) ^ oct;
+                    pend &= pend - 1;
+                    const uint32_t start = lc == 0 ? ra.x : lc == 1 ? ra.y : lc == 2 ? ra.z : lc == 3 ? ra.w : lc == 4 ? rb.x : lc == 5 ? rb.y : lc == 6 ? rb.z : rb.w;
+                    leafQ[((qhead + queued) & (uint32_t)(kLeafQueue - 1)) * kBlockThreads] = start | (chunkMask << 24);
+                    queued++;
+                }
+                timerA.stop(stk, 0);
+            }
+        } else {
+            // ---- one triangle for every lane that has one
+            if (haveTriangles) {
                 SectionTimer<STATS> timerB;
-                tp += 3;
-                const f4_t nA = ld4(tp), nB = ld4(tp + 1), nC = ld4(tp + 2);
-                uint32_t idw = fbits(A.w);
+                if (cursor == kNoTriangle) {    // oldest queued leaf first
+                    const uint32_t e = leafQ[qhead * kBlockThreads];
+                    cursor = e & 0xFFFFFFu; cursorChunks = e >> 24;
+                    qhead = (qhead + 1u) & (uint32_t)(kLeafQueue - 1);
+                    queued--;
+                }
+                const F4* tp = S.tris + (size_t)cursor * 3;
+                const f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
+                const uint32_t idw = fbits(A.w);
                 if (STATS) cnt.triTests++;
                 // Moeller-Trumbore exactly as the reference evaluates it (edges were subtracted on the host)
                 V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
@@ -400,7 +414,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                 float det = dot(e1, pvec);
                 // the reference compares against the double literal -0.01; -0.01f is the smallest float that passes
                 bool rejected = (cull && det >= -0.01f) || (fabsf(det) <= 0);
-                if (meshMode == kMeshEightBoxes) rejected = rejected || (idw & kTriChunkDropped) || !((chunkMask >> ((idw >> kTriChunkShift) & 7u)) & 1u);
+                if (meshMode == kMeshEightBoxes) rejected = rejected || (idw & kTriChunkDropped) || !((cursorChunks >> ((idw >> kTriChunkShift) & 7u)) & 1u);
                 if (!rejected) {
                     float invDet = 1 / det;
                     V3 tvec = o - v0;
@@ -424,13 +438,11 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                         }
                     }
                 }
+                cursor = (idw & kTriLast) ? kNoTriangle : cursor + 1u;
                 timerB.stop(stk, 1);
-                if ((idw & kTriLast) || (ANYHIT && found)) break;
-                A = nA; B = nB; C = nC;
+                if (ANYHIT && found) break;
             }
-            if (ANYHIT && found) { pend = 0; hits = 0; sp = 0; }
         }
-        if (ANYHIT && found) break;
     }
     timerWhole.stop(stk, 3);
     return ANYHIT ? found : false;
@@ -919,9 +931,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     if (!WIDE && fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
     __shared__ uint32_t stackBase[kMaxOctreeDepth * kBlockThreads];
     __shared__ uint32_t stackMask[kMaxOctreeDepth * kBlockThreads];
+    __shared__ uint32_t leafQueue[kLeafQueue * kBlockThreads];
     __shared__ unsigned long long profile[16];  // section accumulators of the instrumented kernel: (cycles, executions) x 8
     const uint32_t lane = threadIdx.x;
-    StackRef stk; stk.base = stackBase + lane; stk.mask = stackMask + lane; stk.prof = profile;
+    StackRef stk; stk.base = stackBase + lane; stk.mask = stackMask + lane; stk.leaves = leafQueue + lane; stk.prof = profile;
     if (STATS) { if (lane < 16) profile[lane] = 0; __syncthreads(); }
 
     // Workgroup B runs on XCD B % 8 (round-robin dispatch).  XCD x takes the tiles at positions x, x + 8, x + 16, ... of the

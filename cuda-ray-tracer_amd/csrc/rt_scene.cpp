@@ -434,8 +434,9 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err, bool
     out.params = params;
     out.maxDepth += forestDepth;
     if (out.maxDepth >= kMaxOctreeDepth) { err = "forest plus octree nesting exceeds the traversal stack"; return false; }
-    // one spare triangle record: the intersection loop requests record i + 1 while it works on record i
-    if (!out.tris.empty()) { for (int k = 0; k < 3; k++) out.tris.push_back(f4(0.0f, 0.0f, 0.0f, 0.0f)); }
+    // spare triangle records: the split waves read eight consecutive records wherever a leaf starts
+    if (!out.tris.empty()) { for (int k = 0; k < 3 * kSpareTriangles; k++) out.tris.push_back(f4(0.0f, 0.0f, 0.0f, 0.0f)); }
+    if (out.triangleCount + kSpareTriangles > (int64_t)kMaxTriangleRecords) { err = "too many triangles in the scene (" + std::to_string(kMaxTriangleRecords) + " records at most)"; return false; }
     out.nodeCount = (int64_t)(out.nodes.size() / kNodeFloat4s);
     out.lightPos[0] = s.lights[0].position.x; out.lightPos[1] = s.lights[0].position.y; out.lightPos[2] = s.lights[0].position.z;
     out.lightCol[0] = s.lights[0].colour.x; out.lightCol[1] = s.lights[0].colour.y; out.lightCol[2] = s.lights[0].colour.z;
