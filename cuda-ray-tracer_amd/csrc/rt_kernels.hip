@@ -338,7 +338,8 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
         if (!moreNodes && !haveTriangles) break;
         const bool canDescend = moreNodes && queued <= (uint32_t)(kLeafQueue - 8);
         const int wantNodes = __builtin_popcountll(__ballot(canDescend)), wantTriangles = __builtin_popcountll(__ballot(haveTriangles));
-        if (wantNodes != 0 && wantNodes >= wantTriangles) {
+        // triangles weigh double in the vote: testing them soon keeps the hit distance that prunes the descent up to date
+        if (wantNodes != 0 && wantNodes >= 2 * wantTriangles) {
             // ---- one node visit for every lane that can take one
             if (canDescend) {
                 SectionTimer<STATS> timerA;
