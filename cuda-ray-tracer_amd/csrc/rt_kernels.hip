@@ -405,8 +405,10 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                     qhead = (qhead + 1u) & (uint32_t)(kLeafQueue - 1);
                     queued--;
                 }
+                // two records per turn (the second is only used if the leaf goes on; the array ends with spare records)
                 const F4* tp = S.tris + (size_t)cursor * 3;
-                const f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
+                const f4_t A0 = ld4(tp), B0 = ld4(tp + 1), C0 = ld4(tp + 2), A1 = ld4(tp + 3), B1 = ld4(tp + 4), C1 = ld4(tp + 5);
+                auto testTriangle = [&](f4_t A, f4_t B, f4_t C) {
                 const uint32_t idw = fbits(A.w);
                 if (STATS) cnt.triTests++;
                 // Moeller-Trumbore exactly as the reference evaluates it (edges were subtracted on the host)
@@ -439,6 +441,10 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                         }
                     }
                 }
+                };
+                testTriangle(A0, B0, C0);
+                uint32_t idw = fbits(A0.w);
+                if (!(idw & kTriLast) && !(ANYHIT && found)) { testTriangle(A1, B1, C1); idw = fbits(A1.w); cursor++; }
                 cursor = (idw & kTriLast) ? kNoTriangle : cursor + 1u;
                 timerB.stop(stk, 1);
                 if (ANYHIT && found) break;
