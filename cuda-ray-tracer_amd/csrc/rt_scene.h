@@ -11,7 +11,7 @@ namespace rt {
 
 struct OctreeParams {
     int maxDepth = 8;        // levels of internal nodes
-    int leafTriangles = 8;   // a node with at most this many triangles is a leaf (8 measured best on MI355X: 4 -> +8 % frame time, 16 -> +7 %)
+    int leafTriangles = 6;   // a node with at most this many triangles is a leaf (measured on MI355X, config 3: 4 -> +2 %, 8 -> +2 %, 16 -> +18 % frame time)
 };
 
 // What the device octree builder needs to know about one model with reachable triangles.
