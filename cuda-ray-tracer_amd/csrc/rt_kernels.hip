@@ -123,6 +123,26 @@ RT_DEV bool boxHit(V3 bmin, V3 bmax, V3 o, V3 d, float& t0) {
     return true;
 }
 
+// Whether boxHit accepts the ray, for callers that do not need the distance.  The six quotients are first formed with
+// the ray's reciprocals (v_rcp_f32, within 2^-22 of the correctly rounded division relative to the quotient); when
+// the slab intervals overlap, or fail to, by more than four times that uncertainty the outcome of boxHit follows
+// without a division.  Everything else - a near-tangent ray, a direction component that is zero or denormal, a box
+// touching the origin - goes through boxHit itself.  rdFinite: all three reciprocals are finite.
+RT_DEV bool boxHitDecision(V3 bmin, V3 bmax, V3 o, V3 d, V3 rd, bool rdFinite) {
+    const float ax = (bmin.x - o.x) * rd.x, bx = (bmax.x - o.x) * rd.x;
+    const float ay = (bmin.y - o.y) * rd.y, by = (bmax.y - o.y) * rd.y;
+    const float az = (bmin.z - o.z) * rd.z, bz = (bmax.z - o.z) * rd.z;
+    const float enter = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fminf(az, bz));
+    const float leave = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fmaxf(az, bz));
+    const float big = fmaxf(fmaxf(fmaxf(fabsf(ax), fabsf(bx)), fmaxf(fabsf(ay), fabsf(by))), fmaxf(fabsf(az), fabsf(bz)));
+    const float margin = big * 1e-6f;
+    const bool sane = rdFinite && big > 1e-30f && big < 1e30f;
+    if (sane && leave - enter > 2 * margin && leave > margin) return true;
+    if (sane && (enter - leave > 2 * margin || leave < -margin)) return false;
+    float t0;
+    return boxHit(bmin, bmax, o, d, t0);
+}
+
 RT_DEV V3 boxNormalAt(V3 bmin, V3 bmax, V3 point) {
     V3 centre = (bmin + bmax) / 2.0f;
     V3 p = point - centre;
@@ -293,6 +313,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
 
     const SlabRay sr = makeSlabRay(o, d);   // approximate arithmetic, used for the child-box tests only
     const uint32_t oct = sr.oct;
+    const bool rdFinite = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
 
     // Is model mm a candidate for this ray at all: not hidden from this ray type, and (whole-box mode) through the
     // reference's exact bounding-box gate.
@@ -300,8 +321,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
         if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) return false;
         if (meshMode == kMeshWholeBox) {
             if (STATS) cnt.gateTests++;
-            float tGate;
-            return boxHit(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, tGate);
+            return boxHitDecision(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, sr.rd, rdFinite);
         }
         return true;
     };
@@ -368,8 +388,7 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
                         chunkMask = 0;
                         for (int b = 0; b < 8; b++) {
                             if (STATS) cnt.gateTests++;
-                            float tGate;
-                            if (boxHit(xyz(ld4(S.mdlChunkMin + 8 * mm + b)), xyz(ld4(S.mdlChunkMax + 8 * mm + b)), o, d, tGate)) chunkMask |= 1u << b;
+                            if (boxHitDecision(xyz(ld4(S.mdlChunkMin + 8 * mm + b)), xyz(ld4(S.mdlChunkMax + 8 * mm + b)), o, d, sr.rd, rdFinite)) chunkMask |= 1u << b;
                         }
                         enter = chunkMask != 0;
                     }
@@ -471,6 +490,7 @@ RT_DEV bool traceModelsWide(const DevScene& S, V3 o, V3 d, bool cull, bool skipD
     const float tmin = positiveOnly ? 0.0f : -__builtin_inff();
     const SlabRay sr = makeSlabRay(o, d);
     const uint32_t oct = sr.oct;
+    const bool rdFinite = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
     float bt = best.t;                            // best hit so far: (t, model, triangle), barycentrics
     int bkind = best.kind, bmm = best.idx, bid = best.tri;
     float bu = best.u, bv = best.v;
@@ -479,8 +499,7 @@ RT_DEV bool traceModelsWide(const DevScene& S, V3 o, V3 d, bool cull, bool skipD
     auto gate = [&](int mm) -> bool {
         if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) return false;
         if (meshMode == kMeshWholeBox) {
-            float tGate;
-            return boxHit(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, tGate);
+            return boxHitDecision(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, sr.rd, rdFinite);
         }
         return true;
     };
@@ -550,8 +569,7 @@ RT_DEV bool traceModelsWide(const DevScene& S, V3 o, V3 d, bool cull, bool skipD
             if (STATS && !pregated && meshMode == kMeshWholeBox) cnt.gateTests++;
             if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: one chunk gate per lane
                 if (STATS) cnt.gateTests += 8;
-                float tGate;
-                const bool chunkHit = boxHit(xyz(ld4(S.mdlChunkMin + 8 * mm + (int)sub)), xyz(ld4(S.mdlChunkMax + 8 * mm + (int)sub)), o, d, tGate);
+                const bool chunkHit = boxHitDecision(xyz(ld4(S.mdlChunkMin + 8 * mm + (int)sub)), xyz(ld4(S.mdlChunkMax + 8 * mm + (int)sub)), o, d, sr.rd, rdFinite);
                 chunkMask = groupBits(chunkHit);
                 enter = chunkMask != 0;
             }

@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 
@@ -52,7 +53,12 @@ public:
         scratch_.resize(tris.size());
     }
 
-    int build() { return tris_.empty() ? -1 : buildRange(0, (int)tris_.size(), 0); }
+    int build() {
+        if (tris_.empty()) return -1;
+        int root = buildRange(0, (int)tris_.size(), 0);
+        if (params_.widen) widen(root);
+        return root;
+    }
 
     std::vector<TreeNode> nodes;
     std::vector<int> perm_;
@@ -99,6 +105,66 @@ private:
             nodes[self].child[c] = childIdx;
         }
         return self;
+    }
+
+    static float area(const Box& b) {
+        const float dx = b.hi[0] - b.lo[0], dy = b.hi[1] - b.lo[1], dz = b.hi[2] - b.lo[2];
+        return dx * dy + dy * dz + dz * dx;
+    }
+
+    // A node of the octree of a surface has about half of its eight slots in use.  This pass fills the free ones: as
+    // long as there is room, the internal child with the largest box (the one a ray is most likely to enter) is replaced
+    // by its own children.  The tree gets shallower and a ray visits fewer nodes for the same triangles.  Afterwards the
+    // children are dealt to the slots so that slot index bit a set still means "towards +a within the node", which is
+    // what the traversal's front-to-back order (slot ^ ray octant) relies on; the order is a heuristic, hits do not
+    // depend on it.
+    void widen(int ni) {
+        if (nodes[ni].leaf) return;
+        std::vector<int> kids;
+        for (int c = 0; c < 8; c++) if (nodes[ni].child[c] >= 0) kids.push_back(nodes[ni].child[c]);
+        for (;;) {
+            int pick = -1;
+            float pickArea = -1.0f;
+            for (size_t i = 0; i < kids.size(); i++) {
+                const TreeNode& k = nodes[kids[i]];
+                if (k.leaf) continue;
+                int grand = 0;
+                for (int c = 0; c < 8; c++) grand += k.child[c] >= 0 ? 1 : 0;
+                if ((int)kids.size() - 1 + grand > 8) continue;
+                const float a = area(k.box);
+                if (a > pickArea) { pickArea = a; pick = (int)i; }
+            }
+            if (pick < 0) break;
+            const int gone = kids[(size_t)pick];
+            kids.erase(kids.begin() + pick);
+            for (int c = 0; c < 8; c++) if (nodes[gone].child[c] >= 0) kids.push_back(nodes[gone].child[c]);
+        }
+        // slots: best total of (child centre - node centre) . (slot direction), greedily
+        const Box& nb = nodes[ni].box;
+        struct Pair { float score; int kid, slot; };
+        std::vector<Pair> pairs;
+        for (size_t i = 0; i < kids.size(); i++) {
+            const Box& kb = nodes[kids[i]].box;
+            float rel[3];
+            for (int a = 0; a < 3; a++) {
+                const float ext = nb.hi[a] - nb.lo[a];
+                rel[a] = ext > 0 ? ((0.5f * kb.lo[a] + 0.5f * kb.hi[a]) - (0.5f * nb.lo[a] + 0.5f * nb.hi[a])) / ext : 0.0f;
+            }
+            for (int s = 0; s < 8; s++) {
+                const float sc = ((s & 1) ? rel[0] : -rel[0]) + ((s & 2) ? rel[1] : -rel[1]) + ((s & 4) ? rel[2] : -rel[2]);
+                pairs.push_back(Pair{sc, (int)i, s});
+            }
+        }
+        std::stable_sort(pairs.begin(), pairs.end(), [](const Pair& a, const Pair& b) { return a.score > b.score; });
+        int slotOf[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        bool kidDone[8] = {false, false, false, false, false, false, false, false};
+        for (const Pair& p : pairs) {
+            if (kidDone[p.kid] || slotOf[p.slot] >= 0) continue;
+            slotOf[p.slot] = kids[(size_t)p.kid];
+            kidDone[p.kid] = true;
+        }
+        for (int c = 0; c < 8; c++) nodes[ni].child[c] = slotOf[c];
+        for (int c = 0; c < 8; c++) if (slotOf[c] >= 0) widen(slotOf[c]);
     }
 
     static int octant(const float c[3], const float mid[3]) {
@@ -380,6 +446,7 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err, bool
     OctreeParams params;
     if (s.octreeMaxDepth > 0) params.maxDepth = s.octreeMaxDepth;
     if (s.octreeLeafTriangles > 0) params.leafTriangles = s.octreeLeafTriangles;
+    if (const char* e = std::getenv("RT_WIDEN")) params.widen = std::atoi(e) != 0;
     if (params.maxDepth > kMaxModelOctreeDepth) { err = "octreeMaxDepth exceeds " + std::to_string(kMaxModelOctreeDepth); return false; }
 
     F4 mat[3];

@@ -259,3 +259,39 @@ def test_octree_flag_renders_meshes_with_whole_box_semantics(renderer, oracle):
     renderer.set_state(built.camera, cfg)
     flagged, _ = renderer.render(192, 108)
     assert np.array_equal(base, flagged)
+
+
+@pytest.mark.parametrize("mode", ["whole", "eight"])
+def test_gate_boxes_cutting_through_meshes_on_exact_pixel_rays(renderer, oracle, mode):
+    """The gates decide from reciprocal-multiplied quotients when the outcome is clear and divide only near a box edge.
+    Here the gate boxes are shrunk so that they cut through the meshes (the gate, not the triangles, decides what is
+    visible), their near faces end exactly on pixel-centre rays of an axis-aligned camera (near-tangent rays, and rays
+    with zero direction components in the centre row and column), and the result must equal the reference arithmetic."""
+    from cuda_ray_tracer_amd import ctypes_types as T
+    spec, cfg, _, _ = scenes.config_scene(2, detail=0.3)
+    spec.cam_pos = (0.0, 12.0, 40.0); spec.cam_yaw = -90.0; spec.cam_pitch = 0.0; spec.fov = 90.0
+    if mode == "eight":
+        cfg.eightBoundingBoxes = 1
+    w = h = 256
+    built = scenes.build_scene(spec)
+    depth = 25.0                                    # camera z - near face z
+    def on_ray(k):                                  # offset at `depth` of the ray through the centre of pixel column / row k
+        return (2.0 * (k + 0.5) / w - 1.0) * depth
+    for i in range(built.desc.modelCount):
+        m = built.desc.models[i]
+        lo_k, hi_k = (100, 140) if i == 0 else (118, 170)
+        m.bbMin = T.Vec3(on_ray(lo_k), 12.0 + on_ray(lo_k + 3), -5.0)
+        m.bbMax = T.Vec3(on_ray(hi_k), 12.0 + on_ray(hi_k + 9), 15.0)
+        for b in range(8):
+            cb = m.boundingBoxes[b]
+            cb.min = T.Vec3(on_ray(lo_k - 10 + 3 * b), cb.min.y, cb.min.z)
+            cb.max = T.Vec3(cb.max.x, 12.0 + on_ray(hi_k + b), 15.0)
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    g_rgb, g_ids, g_t, st = renderer.render_ids(w, h)
+    o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built.desc, built.camera, cfg, w, h, threads=16)
+    stats = compare_frames(g_rgb, g_ids, g_t, o_rgb, o_ids, o_t, None)
+    print("gate edges", mode, stats, st.rays)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+    assert (g_ids[..., 0] >> 24 == 4).sum() > 50, "the shrunk gates should still let some mesh pixels through"
