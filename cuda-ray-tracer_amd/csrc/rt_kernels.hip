@@ -16,6 +16,7 @@
 // child boxes are padded on the host and the test never rejects a box containing an acceptable triangle.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
 
 #include "rt_device_types.h"
 #include "rt_kernels.h"
@@ -30,6 +31,8 @@ constexpr int kBlockThreads = 64;   // render workgroups are single waves
 constexpr uint32_t kSplitSpeedup = 3; // a block rendered by eight split waves is taken to finish this many times sooner
 constexpr int kLeafQueue = 16;       // queued leaves per lane (a node visit can add eight)
 constexpr uint32_t kNoTriangle = 0xFFFFFFFFu;
+constexpr int kNodePool = 512;       // shared-pool traversal: entries of pending children per wave
+constexpr int kTriPool = 560;        // and of pending triangle runs (a node turn can add 8 per lane)
 constexpr int kWaveRecordWords = 18; // per-wave diagnostic record: start, end, 8 x (cycles, executions)
 #define FAR_T 999.0f
 
@@ -198,6 +201,12 @@ struct StackRef {
     uint32_t* base;   // &stackBase[0][tid]
     uint32_t* mask;
     uint32_t* leaves; // &leafQueue[0][tid]: leaves found but not yet intersected
+    // shared-pool traversal (tracePool): everything below is indexed by lane or pool position, not per-lane pointers
+    f4_t* rayO; f4_t* rayD; f4_t* rayR;  // [64] ray of lane l: origin | gate bits low, direction | gate bits high, reciprocal direction | octant
+    unsigned long long* bestKey;         // [64] ordered hit distance << 32 | triangle order key (see tracePool)
+    uint32_t* bestRec;                   // [64] triangle record of the hit in bestKey
+    unsigned long long* nodePool;        // [kNodePool] pending children: node base | (imask | hits << 8 | owner << 16 | chunks << 24) << 32
+    unsigned long long* triPool;         // [kTriPool] pending triangles: first record | (owner | chunks << 8) << 32
     unsigned long long* prof;   // instrumented kernel only: 8 per-wave accumulators in LDS (see renderKernel)
 };
 
@@ -358,6 +367,10 @@ RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug
         if (!moreNodes && !haveTriangles) break;
         const bool canDescend = moreNodes && queued <= (uint32_t)(kLeafQueue - 8);
         const int wantNodes = __builtin_popcountll(__ballot(canDescend)), wantTriangles = __builtin_popcountll(__ballot(haveTriangles));
+        if (STATS) {
+            const unsigned long long any = __ballot(canDescend || haveTriangles), act = __ballot(1);
+            if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)act) - 1)) { stk.prof[14] += (unsigned long long)__builtin_popcountll(any); stk.prof[15] += 1ull + ((unsigned long long)__builtin_popcountll(act) << 32); }
+        }
         // triangles weigh double in the vote: testing them soon keeps the hit distance that prunes the descent up to date
         if (wantNodes != 0 && wantNodes >= 2 * wantTriangles) {
             // ---- one node visit for every lane that can take one
@@ -662,6 +675,265 @@ RT_DEV bool traceModelsWide(const DevScene& S, V3 o, V3 d, bool cull, bool skipD
 
 // ---------------------------------------------------------------- linear object traces
 
+// Float -> unsigned with the same order (negative values below positive ones), and back.
+RT_DEV uint32_t orderBits(float t) { const uint32_t b = fbits(t); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
+RT_DEV float orderFloat(uint32_t m) { return ubits((m & 0x80000000u) ? (m & 0x7fffffffu) : ~m); }
+
+// The same trace with the work of all 64 rays of the wave in two shared pools in LDS: pending children of visited nodes,
+// and pending runs of triangles.  Every turn the wave takes the 64 newest entries of one pool, one per lane, whichever
+// rays they belong to; a lane fetches the ray of its entry from LDS.  With one ray per lane the traversal loop ran with
+// 35 of the 60 lanes that entered it still busy on average (27 in the slowest waves): rays of one 8x8 block need very
+// different numbers of steps.  Here a ray with much work gets the lanes of the rays that are done.
+//
+// All 64 lanes must call this together; hasRay says whether the lane brings a ray.  The nearest hit of ray l is kept in
+// bestKey[l] = orderBits(t) << 32 | key, lowered with a 64-bit LDS atomic minimum; key = the triangle's index in the
+// scene-wide attribute array, which grows with (model, triangle id), so that the minimum implements the reference's tie
+// rule.  The start value holds the distance of the nearest other object with key 0: a triangle must be strictly nearer.
+// bestRec[l] remembers the triangle record of the minimum; when the pools are empty each lane intersects its winning
+// triangle once more to obtain t, u and v (same arithmetic, same values).  An any-hit ray that found something stores
+// 0, and its remaining entries are dropped when they come up.
+//
+// Entries of one ray can be taken in the same turn, so subtrees are entered that a strictly front-to-back traversal
+// would have pruned; what is visited beyond that never changes the result.  Newest-first order keeps that small: the
+// top of the pool are the children just found, nearest child first.
+// Pool capacity: a lane's node turn takes one entry and adds at most two (remaining siblings, new children), so a full
+// turn needs 64 free entries; with fewer, single lanes take turns (depth-first on the newest entry, which needs at most
+// one more entry per tree level) until there is room again.  A node turn adds at most eight triangle runs per lane, and
+// is only taken with at most 64 runs pending.
+template <bool ANYHIT, bool STATS>
+RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, Closest& best, StackRef stk, Counters& cnt) {
+    if (S.forestRoot == kNoRoot) return false;
+    SectionTimer<STATS> timerWhole;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int nMdl = S.nMdl;
+    const bool positiveOnly = meshMode != kMeshNoBox;
+    const float tmin = positiveOnly ? 0.0f : -__builtin_inff();
+    const bool pregated = nMdl <= kPregatedModels;
+
+    // Exact gate of model mm for the ray (ro, rd); see traceModels.
+    auto gate = [&](int mm, V3 ro, V3 rdir, V3 rrd, bool fin) -> bool {
+        if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) return false;
+        if (meshMode == kMeshWholeBox) {
+            if (STATS) cnt.gateTests++;
+            return boxHitDecision(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), ro, rdir, rrd, fin);
+        }
+        return true;
+    };
+
+    const float startT = ANYHIT ? FAR_T : best.t;
+    const unsigned long long init = (unsigned long long)orderBits(startT) << 32;
+    unsigned long long gateBits = 0;
+    if (hasRay && pregated) {
+        SectionTimer<STATS> timerG;
+        const SlabRay sr = makeSlabRay(o, d);
+        const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
+        for (int j = 0; j < nMdl; j++) {
+            if (!tightBoxHit(xyz(ld4(S.mdlTightMin + j)), xyz(ld4(S.mdlTightMax + j)), sr, tmin, startT)) continue;
+            if (gate(j, o, d, sr.rd, fin)) gateBits |= 1ull << j;
+        }
+        timerG.stop(stk, 2);
+    }
+    const bool enters = hasRay && (!pregated || gateBits != 0);
+    {
+        f4_t ro4 = {o.x, o.y, o.z, ubits((uint32_t)gateBits)}, rd4 = {d.x, d.y, d.z, ubits((uint32_t)(gateBits >> 32))};
+        const SlabRay own = makeSlabRay(o, d);
+        f4_t rr4 = {own.rd.x, own.rd.y, own.rd.z, ubits(own.oct)};
+        stk.rayO[lane] = ro4; stk.rayD[lane] = rd4; stk.rayR[lane] = rr4;
+        stk.bestKey[lane] = init;
+    }
+    // one pseudo entry per ray that resolves to the forest root
+    uint32_t nodeCount, triCount = 0;
+    {
+        const unsigned long long m = __ballot(enters);
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        if (enters) stk.nodePool[rank] = (unsigned long long)S.forestRoot | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
+        nodeCount = (uint32_t)__builtin_popcountll(m);
+    }
+    __builtin_amdgcn_wave_barrier();
+
+    while (nodeCount != 0 || triCount != 0) {
+        const bool nodeTurn = nodeCount != 0 && triCount < 40u;    // measured: 16 -> +2 %, 32..48 best, 64 -> +2 % frame time
+        if (nodeTurn) {
+            SectionTimer<STATS> timerA;
+            const uint32_t room = (uint32_t)kNodePool - nodeCount;
+            const uint32_t width = room >= 88u ? 64u : 1u;       // 64 for the turn + more than one entry per tree level for what may follow
+            const uint32_t take = nodeCount < width ? nodeCount : width;
+            const bool mine = lane < take;
+            if (STATS && lane == 0) { stk.prof[14] += take; stk.prof[15] += 1ull + (64ull << 32); }
+            unsigned long long e = 0;
+            if (mine) e = stk.nodePool[nodeCount - 1u - lane];
+            nodeCount -= take;
+            const uint32_t base = (uint32_t)e, packed = (uint32_t)(e >> 32);
+            const uint32_t imask = packed & 0xffu, hits = (packed >> 8) & 0xffu, owner = (packed >> 16) & 63u;
+            uint32_t chunkMask = packed >> 24;
+            unsigned long long bk = 0;
+            if (mine) bk = stk.bestKey[owner];
+            const bool alive = mine && !(ANYHIT && bk == 0ull);
+            // the siblings that are still waiting go back first, so that the children found now end up on top
+            const uint32_t rest = hits & (hits - 1u);
+            {
+                const bool again = alive && rest != 0u;
+                const unsigned long long m = __ballot(again);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (again) stk.nodePool[nodeCount + rank] = (unsigned long long)base | ((unsigned long long)(imask | (rest << 8) | (owner << 16) | (chunkMask << 24)) << 32);
+                nodeCount += (uint32_t)__builtin_popcountll(m);
+            }
+            uint32_t childHits = 0, pend = 0, childBase = 0, childImask = 0, oct = 0;
+            u4_t ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+            if (alive) {
+                const f4_t ro4 = stk.rayO[owner], rr4 = stk.rayR[owner];
+                const V3 ro = xyz(ro4);
+                SlabRay sr;
+                sr.rd = xyz(rr4); sr.ord = mk(ro.x * sr.rd.x, ro.y * sr.rd.y, ro.z * sr.rd.z); sr.oct = fbits(rr4.w);
+                oct = sr.oct;
+                const uint32_t c = (uint32_t)__builtin_ctz(hits) ^ oct;
+                const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
+                const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
+                const u4_t head = *reinterpret_cast<const u4_t*>(np), meta = *reinterpret_cast<const u4_t*>(np + 1);
+                ra = *reinterpret_cast<const u4_t*>(np + 5); rb = *reinterpret_cast<const u4_t*>(np + 6);
+                const float tmax = ANYHIT ? FAR_T : orderFloat((uint32_t)(bk >> 32));
+                uint32_t hmask = testChildren(np, head, sr, tmin, tmax);
+                if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
+                    const int mm = (int)meta.z;
+                    const f4_t rd4 = stk.rayD[owner];
+                    const V3 rdir = xyz(rd4);
+                    const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
+                    const unsigned long long bits = (unsigned long long)fbits(ro4.w) | ((unsigned long long)fbits(rd4.w) << 32);
+                    bool enter = pregated ? (((bits >> mm) & 1ull) != 0) : gate(mm, ro, rdir, sr.rd, fin);
+                    if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
+                        chunkMask = 0;
+                        for (int b = 0; b < 8; b++) {
+                            if (STATS) cnt.gateTests++;
+                            if (boxHitDecision(xyz(ld4(S.mdlChunkMin + 8 * mm + b)), xyz(ld4(S.mdlChunkMax + 8 * mm + b)), ro, rdir, sr.rd, fin)) chunkMask |= 1u << b;
+                        }
+                        enter = chunkMask != 0;
+                    }
+                    if (!enter) hmask = 0;
+                }
+                const uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
+                if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
+                childBase = meta.x; childImask = nodeImask;
+                childHits = permuteOctants(hmask & nodeImask, oct);
+                pend = permuteOctants(hmask & nodeLmask, oct);
+            }
+            {
+                const bool down = childHits != 0u;
+                const unsigned long long m = __ballot(down);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (down) stk.nodePool[nodeCount + rank] = (unsigned long long)childBase | ((unsigned long long)(childImask | (childHits << 8) | (owner << 16) | (chunkMask << 24)) << 32);
+                nodeCount += (uint32_t)__builtin_popcountll(m);
+            }
+            // leaves, farthest first so that the nearest is the newest
+            for (;;) {
+                const bool more = pend != 0u;
+                const unsigned long long m = __ballot(more);
+                if (m == 0ull) break;
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (more) {
+                    const uint32_t k = 31u - (uint32_t)__builtin_clz(pend);
+                    pend &= ~(1u << k);
+                    const uint32_t lc = k ^ oct;
+                    const uint32_t start = lc == 0 ? ra.x : lc == 1 ? ra.y : lc == 2 ? ra.z : lc == 3 ? ra.w : lc == 4 ? rb.x : lc == 5 ? rb.y : lc == 6 ? rb.z : rb.w;
+                    stk.triPool[triCount + rank] = (unsigned long long)start | ((unsigned long long)(owner | (chunkMask << 8)) << 32);
+                }
+                triCount += (uint32_t)__builtin_popcountll(m);
+            }
+            timerA.stop(stk, 0);
+        } else {
+            SectionTimer<STATS> timerB;
+            const uint32_t take = triCount < 64u ? triCount : 64u;
+            const bool mine = lane < take;
+            if (STATS && lane == 0) { stk.prof[14] += take; stk.prof[15] += 1ull + (64ull << 32); }
+            unsigned long long e = 0;
+            if (mine) e = stk.triPool[triCount - 1u - lane];
+            triCount -= take;
+            const uint32_t first = (uint32_t)e, owner = (uint32_t)(e >> 32) & 63u, chunks = (uint32_t)(e >> 40) & 0xffu;
+            unsigned long long bk = 0;
+            if (mine) bk = stk.bestKey[owner];
+            const bool alive = mine && !(ANYHIT && bk == 0ull);
+            bool goesOn = false;
+            if (alive) {
+                const F4* tp = S.tris + (size_t)first * 3;
+                const f4_t A0 = ld4(tp), B0 = ld4(tp + 1), C0 = ld4(tp + 2), A1 = ld4(tp + 3), B1 = ld4(tp + 4), C1 = ld4(tp + 5);
+                const V3 ro = xyz(stk.rayO[owner]), rdir = xyz(stk.rayD[owner]);
+                auto testTriangle = [&](f4_t A, f4_t B, f4_t C, uint32_t record) {
+                    const uint32_t idw = fbits(A.w);
+                    if (STATS) cnt.triTests++;
+                    // Moeller-Trumbore exactly as the reference evaluates it (edges were subtracted on the host)
+                    V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
+                    V3 pvec = cross(rdir, e2);
+                    float det = dot(e1, pvec);
+                    bool rejected = (cull && det >= -0.01f) || (fabsf(det) <= 0);
+                    if (meshMode == kMeshEightBoxes) rejected = rejected || (idw & kTriChunkDropped) || !((chunks >> ((idw >> kTriChunkShift) & 7u)) & 1u);
+                    if (rejected) return;
+                    float invDet = 1 / det;
+                    V3 tvec = ro - v0;
+                    float u = dot(tvec, pvec) * invDet;
+                    if (u < 0 || u > 1) return;
+                    V3 qvec = cross(tvec, e1);
+                    float v = dot(rdir, qvec) * invDet;
+                    if (v < 0 || u + v > 1) return;
+                    float t = dot(e2, qvec) * invDet;
+                    const bool inRange = !positiveOnly || t > 0;      // Model.cpp:287 vs :327
+                    if (!inRange || !(t == t)) return;
+                    if (ANYHIT) {
+                        if (t < FAR_T) stk.bestKey[owner] = 0ull;
+                        return;
+                    }
+                    const int mm = (int)fbits(B.w);
+                    const uint32_t key = S.mdlInfo[4 * mm + 1] + (idw & kTriIdMask);
+                    const unsigned long long cand = ((unsigned long long)orderBits(t + 0.0f) << 32) | key;    // -0 orders as +0
+                    if (cand < bk) {
+                        atomicMin(&stk.bestKey[owner], cand);
+                        // every lane of this turn has applied its minimum by now: only the lane that holds it sees its own value
+                        if (*(volatile unsigned long long*)&stk.bestKey[owner] == cand) stk.bestRec[owner] = record;
+                    }
+                };
+                testTriangle(A0, B0, C0, first);
+                uint32_t idw = fbits(A0.w);
+                if (!(idw & kTriLast)) { testTriangle(A1, B1, C1, first + 1u); idw = fbits(A1.w); }
+                goesOn = !(idw & kTriLast);
+            }
+            {
+                const unsigned long long m = __ballot(goesOn);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (goesOn) stk.triPool[triCount + rank] = (unsigned long long)(first + 2u) | ((unsigned long long)(owner | (chunks << 8)) << 32);
+                triCount += (uint32_t)__builtin_popcountll(m);
+            }
+            timerB.stop(stk, 1);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+
+    bool found = false;
+    if (hasRay) {
+        const unsigned long long bk = stk.bestKey[lane];
+        if (ANYHIT) {
+            found = bk == 0ull;
+        } else if (bk != init) {
+            // the winning triangle once more, for t, u and v
+            const uint32_t record = stk.bestRec[lane];
+            const F4* tp = S.tris + (size_t)record * 3;
+            const f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
+            V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
+            V3 pvec = cross(d, e2);
+            float det = dot(e1, pvec);
+            float invDet = 1 / det;
+            V3 tvec = o - v0;
+            float u = dot(tvec, pvec) * invDet;
+            V3 qvec = cross(tvec, e1);
+            float v = dot(d, qvec) * invDet;
+            float t = dot(e2, qvec) * invDet;
+            best.t = t; best.kind = KIND_MODEL; best.idx = (int)fbits(B.w); best.tri = (int)(fbits(A.w) & kTriIdMask); best.u = u; best.v = v;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    timerWhole.stop(stk, 3);
+    return found;
+}
+
+
+
 // kernels.cu:67-96 over the three analytic object tables, closest hit.  skipDebug* mirror the ray types the
 // reference uses for each table at this level.
 RT_DEV void traceAnalytic(const DevScene& S, V3 o, V3 d, bool skipDebugSpheres, bool tracePlanes, bool skipDebugPlanes,
@@ -923,6 +1195,143 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px
     return c0;
 }
 
+// castSample for the shared-pool mesh trace: the same sequence of rays, with every mesh trace in wave-uniform control flow
+// (all 64 lanes call tracePool; a lane without a ray at that point - outside the frame, chain ended, nothing to shade -
+// passes hasRay = false and lends its lane to the others).  `live`: the lane has a camera sample at all.
+template <bool STATS>
+RT_DEV V3 castSamplePool(const DevScene& S, const FrameParams& P, bool live, V3 o, V3 d, int px, int py, StackRef stk, Counters& cnt, Closest& primaryOut) {
+    const V3 lightPos = mk(S.lightPos), lightCol = mk(S.lightCol), eye = mk(P.camPos), background = mk(P.background);
+    const bool reflections = (P.flags & kCfgReflections) != 0, reflectPlanes = (P.flags & kCfgReflectPlanes) != 0;
+    const bool boxesRun = (P.flags & kCfgRenderBoxes) != 0, modelsRun = (P.flags & kCfgRenderModels) != 0;
+    const bool modelsVisible = modelsRun && (P.flags & kCfgModelsVisible) != 0;
+    const bool hardShadows = (P.flags & kCfgHardShadows) != 0, cull = (P.flags & kCfgCull) != 0;
+
+    V3 lvl0 = background, lvl1 = background, lvl2 = background, lvl3 = background;
+    float str0 = 0, str1 = 0, str2 = 0;
+    bool add0 = false, add1 = false, add2 = false, sh0 = false, sh1 = false, sh2 = false, sh3 = false;
+    float softFactor = 1.0f; bool useSoft = false;
+    int deepest = 0;
+
+    bool active = live;
+    V3 ro = o, rdir = d;
+#pragma unroll 1
+    for (int level = 0; level < 4; level++) {
+        if (__ballot(active) == 0ull) break;
+        Closest h; h.t = FAR_T; h.kind = KIND_NONE; h.idx = -1; h.tri = -1; h.u = 0; h.v = 0;
+        const bool planesRun = (level == 0) || reflectPlanes;
+        if (active) {
+            deepest = level;
+            cnt.rays++;
+            SectionTimer<STATS> tm; traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h); tm.stop(stk, 4);
+        }
+        // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
+        if (modelsVisible) tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, h, stk, cnt);
+        if (level == 0 && active) primaryOut = h;
+        V3 colour = background;
+        bool next = false, lit = false, wantNext = false, add = false, shadowed = false;
+        float strength = 0;
+        V3 biased = mk(0, 0, 0), toLight = mk(0, 0, 1), point = mk(0, 0, 0), normal = mk(0, 0, 1);
+        if (active && h.kind != KIND_NONE) {
+            SectionTimer<STATS> tmShade;
+            Surface s = resolveSurface<STATS>(S, ro, rdir, h, renormCount(h.kind, planesRun, boxesRun, modelsRun), cnt);
+            const bool isDebug = (s.mat.flags & 1u) != 0;
+            if (level == 0 && isDebug) {
+                colour = s.mat.ka;                                          // kernels.cu:309-312
+            } else {
+                V3 nLight = (level == 0 && h.kind == KIND_BOX) ? s.normal : normalise(s.normal);   // kernels.cu:240-245
+                colour = lighting(s.mat, lightPos, lightCol, s.point, eye, nLight, P, px, py);
+                lit = true;
+                point = s.point; normal = s.normal;
+                biased = s.point + s.normal * P.shadowBias;
+                toLight = normalise(lightPos - s.point);
+                if (level == 0) wantNext = reflections && s.mat.type == 1u && !(h.kind == KIND_PLANE && !reflectPlanes);
+                else wantNext = reflections && s.mat.type == 1u && (1 < P.maxDepth) && level < 3;
+                if (wantNext) {
+                    if (h.kind == KIND_PLANE) { strength = P.planeStrength; add = true; }
+                    else if (h.kind == KIND_SPHERE) { strength = P.sphereStrength; add = true; }
+                    else if (h.kind == KIND_MODEL) { strength = P.modelStrength; add = true; }
+                    else if (h.kind == KIND_BOX && level == 0) { strength = P.boxStrength; add = true; }   // kernels.cu:259
+                }
+            }
+            tmShade.stop(stk, 5);
+        }
+        if (level == 0) {
+            // shadow rays of the primary hit: the hard shadow ray (kernels.cu:268-277, stops at the first occluder kind), then
+            // the soft shadow samples (kernels.cu:279-307, every occluder kind counts separately)
+            const int hardRays = hardShadows ? 1 : 0;
+            const bool soft = (P.flags & kCfgSoftShadows) != 0;
+            const int shadowRays = hardRays + (soft ? P.softNum : 0);
+            int hitsCount = 0;
+#pragma unroll 1
+            for (int q = 0; q < shadowRays; q++) {
+                if (__ballot(lit) == 0ull) break;
+                const bool hard = q < hardRays;
+                V3 sd = toLight;
+                bool bySphere = false, byBox = false;
+                if (lit) {
+                    if (!hard) {
+                        V3 ps = lightSampleOffset(sampleSeed(px, py, q - hardRays), P.softRadius);
+                        V3 lightPoint = lightPos + ps;
+                        sd = normalise(lightPoint - point);
+                    }
+                    cnt.rays++;
+                    SectionTimer<STATS> tmSh;
+                    bySphere = shadowSpheres(S, biased, sd);
+                    byBox = (hard && bySphere) ? false : shadowBoxes(S, biased, sd);
+                    tmSh.stop(stk, 6);
+                }
+                bool byModel = false;
+                if (P.flags & kCfgModelsVisible) {   // the shadow traces ignore renderModels (kernels.cu:304)
+                    const bool needModel = lit && !(hard && (bySphere || byBox));
+                    Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
+                    byModel = tracePool<true, STATS>(S, needModel, biased, sd, cull, true, P.meshMode, dummy, stk, cnt);
+                }
+                if (lit) {
+                    if (hard) shadowed = bySphere || byBox || byModel;
+                    else hitsCount += (bySphere ? 1 : 0) + (byBox ? 1 : 0) + (byModel ? 1 : 0);
+                }
+            }
+            if (soft && lit) {
+                softFactor = 1 - ((float)hitsCount / (float)P.softNum);
+                useSoft = true;
+            }
+        } else if (hardShadows && lit) {
+            cnt.rays++;
+            shadowed = shadowSpheres(S, biased, toLight);                                  // kernels.cu:142, 164, 214
+        }
+        if (lit) {
+            if (level == 0) { str0 = strength; add0 = add; sh0 = shadowed; }
+            else if (level == 1) { str1 = strength; add1 = add; sh1 = shadowed; }
+            else if (level == 2) { str2 = strength; add2 = add; sh2 = shadowed; }
+            else { sh3 = shadowed; }
+            if (wantNext) {
+                next = true;
+                V3 r = normalise(reflect(rdir, normal));
+                ro = biased;
+                rdir = r;
+            }
+        }
+        if (active) { if (level == 0) lvl0 = colour; else if (level == 1) lvl1 = colour; else if (level == 2) lvl2 = colour; else lvl3 = colour; }
+        active = active && next;
+    }
+
+    // fold the levels back together in the reference's order of operations
+    V3 c3 = lvl3;
+    if (sh3) c3 = c3 * P.shadowIntensity;                               // kernels.cu:140-144
+    V3 c2 = lvl2;
+    if (sh2) c2 = c2 * P.shadowIntensity;                               // kernels.cu:162-166 (before the add)
+    if (deepest >= 3 && add2) c2 = c2 + c3 * str2;                      // kernels.cu:168-180
+    V3 c1 = lvl1;
+    if (deepest >= 2 && add1) c1 = c1 + c2 * str1;                      // kernels.cu:198-210
+    if (sh1) c1 = c1 * P.shadowIntensity;                               // kernels.cu:212-216 (after the add)
+    V3 c0 = lvl0;
+    if (deepest >= 1 && add0) c0 = c0 + c1 * str0;                      // kernels.cu:248-266
+    if (sh0) c0 = c0 * P.shadowIntensity;                               // kernels.cu:268-277
+    if (useSoft) c0 = c0 * softFactor;                                  // kernels.cu:306
+    return c0;
+}
+
+
 RT_DEV V3 rasterToCameraSpace(const FrameParams& P, float x, float y) {
     float ndcx = x / (float)P.width, ndcy = y / (float)P.height;
     float sx = 2 * ndcx - 1, sy = 1 - 2 * ndcy;
@@ -946,7 +1355,7 @@ RT_DEV uint32_t evenBits3(uint32_t v) { return (v & 1u) | ((v >> 1) & 2u) | ((v 
 
 // WIDE = false: one wave per 8x8 pixel block, one lane per pixel.  WIDE = true: the waves listed in fb.extraMap, each
 // rendering one pixel row of one of the frame's heaviest blocks with eight lanes per ray.
-template <bool STATS, bool WIDE>
+template <bool STATS, bool WIDE, bool POOL>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3))) void renderKernel(DevScene S, FrameParams P, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
                                                     float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
                                                     unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
@@ -954,12 +1363,20 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
     const unsigned long long cyclesStart = tileCost ? __builtin_readcyclecounter() : 0ull;
     if (!WIDE && fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
-    __shared__ uint32_t stackBase[kMaxOctreeDepth * kBlockThreads];
-    __shared__ uint32_t stackMask[kMaxOctreeDepth * kBlockThreads];
-    __shared__ uint32_t leafQueue[kLeafQueue * kBlockThreads];
+    // per-lane traversal state (one ray per lane, eight lanes per ray), or the shared pools of tracePool
+    constexpr int kLaneStateWords = POOL ? 1 : kMaxOctreeDepth * kBlockThreads;
+    __shared__ uint32_t stackBase[kLaneStateWords];
+    __shared__ uint32_t stackMask[kLaneStateWords];
+    __shared__ uint32_t leafQueue[POOL ? 1 : kLeafQueue * kBlockThreads];
+    __shared__ f4_t poolRays[POOL ? 3 * kBlockThreads : 1];
+    __shared__ unsigned long long poolBest[POOL ? kBlockThreads : 1];
+    __shared__ uint32_t poolRec[POOL ? kBlockThreads : 1];
+    __shared__ unsigned long long poolNodes[POOL ? kNodePool : 1];
+    __shared__ unsigned long long poolTris[POOL ? kTriPool : 1];
     __shared__ unsigned long long profile[16];  // section accumulators of the instrumented kernel: (cycles, executions) x 8
     const uint32_t lane = threadIdx.x;
     StackRef stk; stk.base = stackBase + lane; stk.mask = stackMask + lane; stk.leaves = leafQueue + lane; stk.prof = profile;
+    stk.rayO = poolRays; stk.rayD = poolRays + kBlockThreads; stk.rayR = poolRays + 2 * kBlockThreads; stk.bestKey = poolBest; stk.bestRec = poolRec; stk.nodePool = poolNodes; stk.triPool = poolTris;
     if (STATS) { if (lane < 16) profile[lane] = 0; __syncthreads(); }
 
     // Workgroup B runs on XCD B % 8 (round-robin dispatch).  XCD x takes the tiles at positions x, x + 8, x + 16, ... of the
@@ -1008,7 +1425,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
 
     Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0;
-    if (x < P.width && y < P.height) {
+    const bool inFrame = x < P.width && y < P.height;
+    if (POOL || inFrame) {      // the shared-pool trace needs all 64 lanes, also those outside the frame
         const V3 camPos = mk(P.camPos);
         V3 col;
         Closest primary; primary.t = FAR_T; primary.kind = KIND_NONE; primary.idx = -1; primary.tri = -1; primary.u = 0; primary.v = 0;
@@ -1023,12 +1441,14 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
             const float offX = antiAlias ? ((sIdx & 2) ? 0.75f : 0.25f) : 0.5f, offY = antiAlias ? ((sIdx & 1) ? 0.75f : 0.25f) : 0.5f;
             V3 p = rasterToCameraSpace(P, (float)x + offX, (float)y + offY);
             Closest ph;
-            V3 c = castSample<STATS, WIDE>(S, P, camPos, normalise(p), x, y, stk, cnt, ph);
+            V3 c;
+            if (POOL) c = castSamplePool<STATS>(S, P, inFrame, camPos, normalise(p), x, y, stk, cnt, ph);
+            else c = castSample<STATS, WIDE>(S, P, camPos, normalise(p), x, y, stk, cnt, ph);
             if (sIdx == 0) primary = ph;
             total = antiAlias ? total + c : c;
         }
         col = antiAlias ? total / 4.0f : total;
-        if (!splitWave || (lane & 7u) == 0u) {      // the eight lanes of a split wave's pixel hold the same result
+        if (inFrame && (!splitWave || (lane & 7u) == 0u)) {      // the eight lanes of a split wave's pixel hold the same result
             size_t pix;
             if (P.compactOutput) pix = (size_t)localTile * (RT_TILE_PX * RT_TILE_PX) + (size_t)ly * RT_TILE_PX + lx;
             else pix = (size_t)y * (size_t)P.width + (size_t)x;
@@ -1129,8 +1549,14 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
                         const uint32_t* tileOrder, uint32_t* tileCost, BlockFeedback fb) {
     if (P.ownedTiles <= 0) return hipSuccess;
     dim3 grid(launchGridBlocks(P)), block(kBlockThreads);
-    if (stats) hipLaunchKernelGGL((renderKernel<true, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
-    else hipLaunchKernelGGL((renderKernel<false, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
+    static const bool pool = !(std::getenv("RT_POOL") && std::atoi(std::getenv("RT_POOL")) == 0);
+    if (pool) {
+        if (stats) hipLaunchKernelGGL((renderKernel<true, false, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
+        else hipLaunchKernelGGL((renderKernel<false, false, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
+    } else {
+        if (stats) hipLaunchKernelGGL((renderKernel<true, false, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
+        else hipLaunchKernelGGL((renderKernel<false, false, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
+    }
     return hipGetLastError();
 }
 
@@ -1139,8 +1565,8 @@ hipError_t launchRenderWide(const DevScene& S, const FrameParams& P, uint8_t* ou
                             uint32_t* tileCost, BlockFeedback fb) {
     if (P.ownedTiles <= 0 || !P.split) return hipSuccess;
     dim3 grid((unsigned)kMaxExtraWaves), block(kBlockThreads);
-    if (stats) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
-    else hipLaunchKernelGGL((renderKernel<false, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
+    if (stats) hipLaunchKernelGGL((renderKernel<true, true, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
+    else hipLaunchKernelGGL((renderKernel<false, true, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
     return hipGetLastError();
 }
 
@@ -1250,7 +1676,7 @@ int residentRenderWaves() {
     int device = 0, cus = 0, perCu = 0;
     if (hipGetDevice(&device) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<false, false>, kBlockThreads, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<false, false, true>, kBlockThreads, 0) != hipSuccess) return 0;
     return cus * perCu;
 }
 

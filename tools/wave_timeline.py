@@ -52,6 +52,9 @@ for label, sel in (("all waves", np.ones(len(dur), bool)), ("heavy 1% waves", he
                                                                             sec[sel, 2 * k].sum() / max(sec[sel, 2 * k + 1].sum(), 1)) for k in range(7)))
 for label, sel in (("all waves", np.ones(len(dur), bool)), ("heavy 1% waves", heavy)):
     print(label + ", lanes active per execution: " + ", ".join("%s %.1f" % (names[k], lanes[sel, k].sum() / max(sec[sel, 2 * k + 1].sum(), 1)) for k in range(7)))
+for label, sel in (("all waves", np.ones(len(dur), bool)), ("heavy 1% waves", heavy)):
+    turns = sec[sel, 15].sum()
+    print(label + ": traversal turns %.0f/wave, lanes (pool entries) with work %.1f, lanes inside the trace call %.1f" % (sec[sel, 15].mean(), raw[sel, 14].astype(np.float64).sum() / max(turns, 1), lanes[sel, 7].sum() / max(turns, 1)))
 print("heavy 1%% waves: whole mesh traces %.1f%% of their time (%.0f calls/wave, %.0f cyc/call)" % (
     100 * sec[heavy, 6].sum() / tot_cycles[heavy].sum(), sec[heavy, 7].mean(), sec[heavy, 6].sum() / max(sec[heavy, 7].sum(), 1)))
 print("slowest waves (wave index, start us, dur us):", [(int(i), round(float((clk[i, 0] - t0) / 100.0), 1), round(float((clk[i, 1] - clk[i, 0]) / 100.0), 1)) for i in idx])
