@@ -28,7 +28,7 @@ typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 
 #define RT_DEV __device__ __forceinline__
 constexpr int kBlockThreads = 64;   // render workgroups are single waves
-constexpr uint32_t kSplitSpeedup = 3; // a block rendered by eight split waves is taken to finish this many times sooner
+constexpr uint32_t kSplitGainNum = 5, kSplitGainDen = 3;   // a block rendered by eight split waves is taken to finish 5/3 times sooner (measured: 1.65)
 constexpr int kLeafQueue = 16;       // queued leaves per lane (a node visit can add eight)
 constexpr uint32_t kNoTriangle = 0xFFFFFFFFu;
 constexpr int kNodePool = 512;       // shared-pool traversal: entries of pending children per wave
@@ -790,7 +790,6 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
                 const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
                 const u4_t head = *reinterpret_cast<const u4_t*>(np), meta = *reinterpret_cast<const u4_t*>(np + 1);
-                ra = *reinterpret_cast<const u4_t*>(np + 5); rb = *reinterpret_cast<const u4_t*>(np + 6);
                 const float tmax = ANYHIT ? FAR_T : orderFloat((uint32_t)(bk >> 32));
                 uint32_t hmask = testChildren(np, head, sr, tmin, tmax);
                 if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
@@ -815,6 +814,8 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 childBase = meta.x; childImask = nodeImask;
                 childHits = permuteOctants(hmask & nodeImask, oct);
                 pend = permuteOctants(hmask & nodeLmask, oct);
+                // the leaf references are fetched only by the lanes that hit a leaf (the line is in the L1 by now)
+                if (pend != 0u) { ra = *reinterpret_cast<const u4_t*>(np + 5); rb = *reinterpret_cast<const u4_t*>(np + 6); }
             }
             {
                 const bool down = childHits != 0u;
@@ -1421,11 +1422,14 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     // the waves of a tile walk it in Z order (neighbours in time are neighbours on screen).  A regular wave renders the whole
     // 8x8 block, lane l = pixel (l & 7, l >> 3); a split wave renders row `sub` of the block with eight lanes per pixel.
     const uint32_t bx = evenBits3(inTile) * 8u, by = evenBits3(inTile >> 1) * 8u;
-    const uint32_t lx = bx + (splitWave ? (lane >> 3) : (lane & 7u)), ly = by + (splitWave ? sub : (lane >> 3));
+    // (with the shared-pool trace a split wave has eight live lanes, one per pixel of the row, and 56 lanes that only help)
+    constexpr bool replicated = WIDE && !POOL;    // eight lanes compute the same pixel
+    const bool rowLane = !(WIDE && POOL) || lane < 8u;
+    const uint32_t lx = bx + (replicated ? (lane >> 3) : (lane & 7u)), ly = by + (splitWave ? sub : (lane >> 3));
     const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
 
     Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0;
-    const bool inFrame = x < P.width && y < P.height;
+    const bool inFrame = rowLane && x < P.width && y < P.height;
     if (POOL || inFrame) {      // the shared-pool trace needs all 64 lanes, also those outside the frame
         const V3 camPos = mk(P.camPos);
         V3 col;
@@ -1448,7 +1452,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
             total = antiAlias ? total + c : c;
         }
         col = antiAlias ? total / 4.0f : total;
-        if (inFrame && (!splitWave || (lane & 7u) == 0u)) {      // the eight lanes of a split wave's pixel hold the same result
+        if (inFrame && (!replicated || (lane & 7u) == 0u)) {      // the eight lanes of a split wave's pixel hold the same result
             size_t pix;
             if (P.compactOutput) pix = (size_t)localTile * (RT_TILE_PX * RT_TILE_PX) + (size_t)ly * RT_TILE_PX + lx;
             else pix = (size_t)y * (size_t)P.width + (size_t)x;
@@ -1466,7 +1470,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
             }
         }
     }
-    if (splitWave && (lane & 7u) != 0u) { cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; }
+    if (replicated && (lane & 7u) != 0u) { cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; }
 
     if (STATS && waveClocks && lane == 0) {      // diagnostic: when this wave started and finished, and its section sums
         unsigned long long* rec = waveClocks + kWaveRecordWords * (size_t)blockIdx.x;
@@ -1480,7 +1484,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
         // little below the measured speed-up (2.7) so that a block never looks heavier split than it was unsplit, which
         // would keep a frame that does not profit from splitting in the split state.
         const uint32_t own = (uint32_t)(spent >> 6) + 1u;
-        const uint32_t cost = splitWave ? own * 5u / 2u : own;
+        const uint32_t cost = splitWave ? own * 3u / 2u : own;
         atomicMax(&tileCost[localTile], cost);   // a tile is as urgent as its slowest wave
         if (fb.blockCost) atomicMax(&fb.blockCost[localTile * (uint32_t)kWavesPerTile + inTile], cost);
     }
@@ -1565,6 +1569,12 @@ hipError_t launchRenderWide(const DevScene& S, const FrameParams& P, uint8_t* ou
                             uint32_t* tileCost, BlockFeedback fb) {
     if (P.ownedTiles <= 0 || !P.split) return hipSuccess;
     dim3 grid((unsigned)kMaxExtraWaves), block(kBlockThreads);
+    static const bool pool = !(std::getenv("RT_POOL_SPLIT") && std::atoi(std::getenv("RT_POOL_SPLIT")) == 0);
+    if (pool) {
+        if (stats) hipLaunchKernelGGL((renderKernel<true, true, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
+        else hipLaunchKernelGGL((renderKernel<false, true, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
+        return hipGetLastError();
+    }
     if (stats) hipLaunchKernelGGL((renderKernel<true, true, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
     else hipLaunchKernelGGL((renderKernel<false, true, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
     return hipGetLastError();
@@ -1628,9 +1638,10 @@ __global__ __launch_bounds__(256) void selectHeavyKernel(uint32_t* __restrict__ 
                 above += st->binSum[slot][b];
                 const int e = b >> 1;
                 const unsigned long long edge = (unsigned long long)(2 + (b & 1)) << (e - 1);      // lower edge of bin b
-                const unsigned long long extra = above * (8u - kSplitSpeedup) / kSplitSpeedup;
+                const unsigned long long extra = above * (8u * kSplitGainDen - kSplitGainNum) / kSplitGainNum;
                 const unsigned long long bulk = (total + ((extra * ratio256) >> 8)) * 5u / 4u / (slots ? slots : 1u);
-                unsigned long long time = maxCost / kSplitSpeedup > edge ? maxCost / kSplitSpeedup : edge;
+                const unsigned long long splitMax = (unsigned long long)maxCost * kSplitGainDen / kSplitGainNum;
+                unsigned long long time = splitMax > edge ? splitMax : edge;
                 if (bulk > time) time = bulk;
                 if (time < bestTime && time * 10u < unsplitTime * 9u) { bestTime = time; best = b; }
             }

@@ -57,4 +57,9 @@ for label, sel in (("all waves", np.ones(len(dur), bool)), ("heavy 1% waves", he
     print(label + ": traversal turns %.0f/wave, lanes (pool entries) with work %.1f, lanes inside the trace call %.1f" % (sec[sel, 15].mean(), raw[sel, 14].astype(np.float64).sum() / max(turns, 1), lanes[sel, 7].sum() / max(turns, 1)))
 print("heavy 1%% waves: whole mesh traces %.1f%% of their time (%.0f calls/wave, %.0f cyc/call)" % (
     100 * sec[heavy, 6].sum() / tot_cycles[heavy].sum(), sec[heavy, 7].mean(), sec[heavy, 6].sum() / max(sec[heavy, 7].sum(), 1)))
+allidx = np.nonzero(valid)[0]
+extra = allidx >= (len(clk) - 4096)
+if extra.any():
+    print("split waves: %d, duration percentiles (us): %s, sum %.1f ms" % (extra.sum(), {p: round(float(np.percentile(dur[extra], p)), 1) for p in (50, 90, 99, 100)}, dur[extra].sum() / 1e3))
+    print("regular waves: duration percentiles (us): %s" % ({p: round(float(np.percentile(dur[~extra], p)), 1) for p in (50, 90, 99, 99.9, 100)},))
 print("slowest waves (wave index, start us, dur us):", [(int(i), round(float((clk[i, 0] - t0) / 100.0), 1), round(float((clk[i, 1] - clk[i, 0]) / 100.0), 1)) for i in idx])
