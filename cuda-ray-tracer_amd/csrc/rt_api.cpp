@@ -86,7 +86,7 @@ struct rt_ctx {
     int splitStartTenths = 16;        // splitting starts when the heaviest block exceeds this many tenths of the evenly packed frame
     uint32_t splitFloor = 1500;       // ... and at least this much (wave cycles / 64)
     int residentWaves = 0;
-    hipStream_t wideStream = nullptr;  // the split waves run beside the regular ones
+    hipStream_t splitStream = nullptr;  // the split waves run beside the regular ones
     hipEvent_t evFork = nullptr, evJoin = nullptr;
     // Host-mapped word the selection kernel writes the number of split waves to.  Read without synchronising: a stale value
     // only decides whether a frame uses split waves at all (with split = 0 the regular waves render every block).
@@ -197,10 +197,10 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
     if (launch.split) {
         // fork: the split waves of the heaviest blocks start first, on their own stream, and run beside the regular waves
         RT_HIP(hipEventRecord(ctx->evFork, stream));
-        RT_HIP(hipStreamWaitEvent(ctx->wideStream, ctx->evFork, 0));
-        unsigned long long* wideClocks = waveClocks ? waveClocks + (size_t)rt::launchGridBlocks(launch) * RT_WAVE_RECORD_WORDS : nullptr;
-        RT_HIP(rt::launchRenderWide(ctx->scene, launch, out, ids, tbuf, counters, instrumented, ctx->wideStream, wideClocks, cur, fb));
-        RT_HIP(hipEventRecord(ctx->evJoin, ctx->wideStream));
+        RT_HIP(hipStreamWaitEvent(ctx->splitStream, ctx->evFork, 0));
+        unsigned long long* splitClocks = waveClocks ? waveClocks + (size_t)rt::launchGridBlocks(launch) * RT_WAVE_RECORD_WORDS : nullptr;
+        RT_HIP(rt::launchRenderSplit(ctx->scene, launch, out, ids, tbuf, counters, instrumented, ctx->splitStream, splitClocks, cur, fb));
+        RT_HIP(hipEventRecord(ctx->evJoin, ctx->splitStream));
     }
     RT_HIP(rt::launchRender(ctx->scene, launch, out, ids, tbuf, counters, instrumented, stream, waveClocks,
                             plan.haveOrder ? ctx->dTileOrder : nullptr, cur, fb));
@@ -298,7 +298,7 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
         // highest priority: the split waves must get wave slots ahead of the regular waves of the same frame
         int leastPriority = 0, greatestPriority = 0;
         hipError_t se = hipDeviceGetStreamPriorityRange(&leastPriority, &greatestPriority);
-        if (se == hipSuccess) se = hipStreamCreateWithPriority(&c->wideStream, hipStreamNonBlocking, greatestPriority);
+        if (se == hipSuccess) se = hipStreamCreateWithPriority(&c->splitStream, hipStreamNonBlocking, greatestPriority);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming);
         void* hp = nullptr;
@@ -351,7 +351,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->dSplitState) (void)hipFree(ctx->dSplitState);
     if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
     if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
-    if (ctx->wideStream) (void)hipStreamDestroy(ctx->wideStream);
+    if (ctx->splitStream) (void)hipStreamDestroy(ctx->splitStream);
     if (ctx->hSplitWaves) (void)hipHostFree(const_cast<uint32_t*>(ctx->hSplitWaves));
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
@@ -394,7 +394,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
         ctx->nodeFloat4s = built.nodeCount * rt::kNodeFloat4s;
         ctx->triFloat4s = built.triangleRecords * 3;
         bytes += (ctx->nodeFloat4s + ctx->triFloat4s + flat.triangleCount * rt::kAttrFloat4s) * (int64_t)sizeof(rt::F4);
-        if (flat.maxDepth >= rt::kMaxOctreeDepth) { freeScene(ctx); return fail(RT_ERR_INVALID, "forest plus octree nesting exceeds the traversal stack"); }
+        if (flat.maxDepth >= rt::kMaxOctreeDepth) { freeScene(ctx); return fail(RT_ERR_INVALID, "forest plus octree nesting exceeds the depth the traversal reserves pool entries for"); }
     } else {
         if ((rc = uploadArray(flat.nodes, &d.nodes, A, bytes)) || (rc = uploadArray(flat.tris, &d.tris, A, bytes)) ||
             (rc = uploadArray(flat.attrs, &d.attrs, A, bytes))) {

@@ -31,7 +31,7 @@ namespace rt {
 constexpr int kNodeFloat4s = 8;
 constexpr uint32_t kNoRoot = 0xFFFFFFFFu;     // model without triangles / scene without mesh triangles
 constexpr uint32_t kNoModel = 0xFFFFFFFFu;
-constexpr int kMaxOctreeDepth = 16;           // nesting levels (forest + model octree) the traversal stack can hold
+constexpr int kMaxOctreeDepth = 16;           // nesting levels (forest + model octree); the traversal keeps pool entries in reserve for a depth-first descent of this many levels
 constexpr int kMaxModelOctreeDepth = 10;      // cap on the per-model build depth
 constexpr int kPregatedModels = 64;           // up to this many models the gates are evaluated once per ray, up front
 
@@ -125,7 +125,7 @@ enum : int32_t {
 // Feedback from one frame to the next of the same geometry.  The frame is as long as its slowest wave, and a handful of
 // 8x8 pixel blocks (reflective silhouettes) run ten times longer than the rest: every block records its cost, a small
 // kernel compares each block with the time the whole frame would need if its work were spread evenly, and the next
-// frame renders the blocks that are worth it with eight waves each (one per pixel row, eight lanes per ray), started
+// frame renders the blocks that are worth it with eight waves each (one per pixel row: eight rays, and 56 lanes that only help with the traversal), started
 // before everything else.
 struct BlockFeedback {
     uint32_t* blockCost;       // per block (tile * 64 + block in tile): cost recorded by the frame being rendered

@@ -17,7 +17,7 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
 
 // The split waves of the frame's heaviest blocks (fb.extraMap), kMaxExtraWaves workgroups; meant to run concurrently with
 // launchRender of the same frame on another stream.  waveClocks, if given, receives kMaxExtraWaves records.
-hipError_t launchRenderWide(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
+hipError_t launchRenderSplit(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
                             unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
                             uint32_t* tileCost, BlockFeedback fb);
 

@@ -1,4 +1,5 @@
-// gfx950 render kernels: one lane per pixel, one wave per 8x8 pixel tile.
+// gfx950 render kernels: one wave per 8x8 pixel block, one lane per pixel; the mesh traversal is a wave-wide operation in
+// which the lanes share the work of all 64 rays (tracePool).
 //
 // Behavioural contract (what each routine must reproduce, reference file:line):
 //   frame loop / pixel pack      kernels.cu:320-364        camera ray          Camera.cpp:22-38
@@ -29,10 +30,8 @@ typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 #define RT_DEV __device__ __forceinline__
 constexpr int kBlockThreads = 64;   // render workgroups are single waves
 constexpr uint32_t kSplitGainNum = 5, kSplitGainDen = 3;   // a block rendered by eight split waves is taken to finish 5/3 times sooner (measured: 1.65)
-constexpr int kLeafQueue = 16;       // queued leaves per lane (a node visit can add eight)
-constexpr uint32_t kNoTriangle = 0xFFFFFFFFu;
-constexpr int kNodePool = 512;       // shared-pool traversal: entries of pending children per wave
-constexpr int kTriPool = 560;        // and of pending triangle runs (a node turn can add 8 per lane)
+constexpr int kNodePool = 512;       // mesh traversal: entries of pending children per wave
+constexpr int kTriPool = 560;        // and of pending triangle runs (a node turn can add 8 per lane to fewer than 40)
 constexpr int kWaveRecordWords = 18; // per-wave diagnostic record: start, end, 8 x (cycles, executions)
 #define FAR_T 999.0f
 
@@ -196,12 +195,8 @@ struct Closest {
 
 struct Counters { uint32_t rays, nodeTests, triTests, attrFetches, gateTests; };
 
-// Per-block traversal stack in LDS: one entry per internal level, [level][thread] so lanes hit distinct banks.
-struct StackRef {
-    uint32_t* base;   // &stackBase[0][tid]
-    uint32_t* mask;
-    uint32_t* leaves; // &leafQueue[0][tid]: leaves found but not yet intersected
-    // shared-pool traversal (tracePool): everything below is indexed by lane or pool position, not per-lane pointers
+// The wave's working set in LDS for the mesh traversal (tracePool); everything is indexed by lane or by pool position.
+struct WaveLds {
     f4_t* rayO; f4_t* rayD; f4_t* rayR;  // [64] ray of lane l: origin | gate bits low, direction | gate bits high, reciprocal direction | octant
     unsigned long long* bestKey;         // [64] ordered hit distance << 32 | triangle order key (see tracePool)
     uint32_t* bestRec;                   // [64] triangle record of the hit in bestKey
@@ -216,7 +211,7 @@ template <bool STATS>
 struct SectionTimer {
     unsigned long long t0;
     RT_DEV SectionTimer() : t0(STATS ? __builtin_readcyclecounter() : 0ull) {}
-    RT_DEV void stop(const StackRef& stk, int slot) {
+    RT_DEV void stop(const WaveLds& stk, int slot) {
         if (STATS) {
             unsigned long long dt = __builtin_readcyclecounter() - t0;
             unsigned long long active = __ballot(1);
@@ -304,404 +299,43 @@ RT_DEV bool tightBoxHit(V3 lo, V3 hi, const SlabRay& r, float tmin, float tmax) 
     return tn <= tf;
 }
 
-// Traces (o, d) against every eligible model.
-//   ANYHIT = false: closest hit, merged into `best` (which must not hold a model hit yet) with the reference's tie rules:
-//                   strictly nearer than any other kind of object found earlier; among triangles an exact tie goes to
-//                   the lower model index, then the lower triangle index.
-//   ANYHIT = true : returns true as soon as some non-debug model has a triangle with 0 < t < 999.
-// skipDebug: models flagged debug are not candidates (reflection and shadow rays).
-// meshMode (kMesh*): which gates apply and whether a hit needs t > 0 - see Model.cpp:220-356.
-template <bool ANYHIT, bool STATS>
-RT_DEV bool traceModels(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, Closest& best, StackRef stk, Counters& cnt) {
-    if (S.forestRoot == kNoRoot) return false;
-    SectionTimer<STATS> timerWhole;
-    const int nMdl = S.nMdl;
-    const bool positiveOnly = meshMode != kMeshNoBox;
-    const float tmin = positiveOnly ? 0.0f : -__builtin_inff();
-    uint32_t chunkMask = 0xffu;     // eight-box mode: which chunk boxes of the current model the ray passes
-
-    const SlabRay sr = makeSlabRay(o, d);   // approximate arithmetic, used for the child-box tests only
-    const uint32_t oct = sr.oct;
-    const bool rdFinite = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
-
-    // Is model mm a candidate for this ray at all: not hidden from this ray type, and (whole-box mode) through the
-    // reference's exact bounding-box gate.
-    auto gate = [&](int mm) -> bool {
-        if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) return false;
-        if (meshMode == kMeshWholeBox) {
-            if (STATS) cnt.gateTests++;
-            return boxHitDecision(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, sr.rd, rdFinite);
-        }
-        return true;
-    };
-
-    // Small scenes: evaluate every gate up front.  All lanes run the same trip count here, so the exact gate (six
-    // divisions per model) is not serialised across lanes the way it is when each lane meets a model root at its own
-    // time.  The cheap conservative test of the triangles' own box comes first; the order does not change the result.
-    const bool pregated = nMdl <= kPregatedModels;
-    unsigned long long gateBits = 0;
-    if (pregated) {
-        SectionTimer<STATS> timerG;
-        for (int j = 0; j < nMdl; j++) {
-            if (!tightBoxHit(xyz(ld4(S.mdlTightMin + j)), xyz(ld4(S.mdlTightMax + j)), sr, tmin, ANYHIT ? FAR_T : best.t)) continue;
-            if (gate(j)) gateBits |= 1ull << j;
-        }
-        timerG.stop(stk, 2);
-        if (gateBits == 0) { timerWhole.stop(stk, 3); return false; }
-    }
-
-    // children still to visit below the current node; the start state is one pseudo child that resolves to the forest root
-    uint32_t base = S.forestRoot, imask = 0, hits = 1;
-    int sp = 0;
-    // Leaves are not intersected where they are found: a lane queues them (first triangle | chunk mask << 24) and keeps
-    // descending, and the wave turns to triangles when most of its lanes have some - one triangle per lane and turn, a
-    // lane whose leaf ends takes its next one at once.  With leaves intersected on the spot the triangle loop ran with 15
-    // of 64 lanes active on average (leaf lengths differ, and most lanes are descending at any moment).
-    uint32_t queued = 0, qhead = 0, cursor = kNoTriangle, cursorChunks = 0xffu;     // the queue is a ring of kLeafQueue entries
-    uint32_t* leafQ = stk.leaves;
-    bool found = false;
-
-    for (;;) {
-        const bool moreNodes = hits != 0 || sp > 0;
-        const bool haveTriangles = queued != 0 || cursor != kNoTriangle;
-        if (!moreNodes && !haveTriangles) break;
-        const bool canDescend = moreNodes && queued <= (uint32_t)(kLeafQueue - 8);
-        const int wantNodes = __builtin_popcountll(__ballot(canDescend)), wantTriangles = __builtin_popcountll(__ballot(haveTriangles));
-        if (STATS) {
-            const unsigned long long any = __ballot(canDescend || haveTriangles), act = __ballot(1);
-            if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)act) - 1)) { stk.prof[14] += (unsigned long long)__builtin_popcountll(any); stk.prof[15] += 1ull + ((unsigned long long)__builtin_popcountll(act) << 32); }
-        }
-        // triangles weigh double in the vote: testing them soon keeps the hit distance that prunes the descent up to date
-        if (wantNodes != 0 && wantNodes >= 2 * wantTriangles) {
-            // ---- one node visit for every lane that can take one
-            if (canDescend) {
-                SectionTimer<STATS> timerA;
-                if (hits == 0) {
-                    sp--;                       // siblings left on an upper level
-                    base = stk.base[sp * kBlockThreads];
-                    uint32_t packed = stk.mask[sp * kBlockThreads];
-                    imask = packed & 0xffu;
-                    hits = packed >> 8;
-                }
-                uint32_t k = __builtin_ctz(hits);
-                hits &= hits - 1;
-                uint32_t c = k ^ oct;
-                const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
-
-                // The whole 128-byte record is requested at once and nothing below branches before the box test, so a node
-                // visit costs one memory round trip (leaf references included, whether or not a leaf is hit).
-                const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
-                const u4_t head = *reinterpret_cast<const u4_t*>(np), meta = *reinterpret_cast<const u4_t*>(np + 1);
-                const u4_t ra = *reinterpret_cast<const u4_t*>(np + 5), rb = *reinterpret_cast<const u4_t*>(np + 6);
-                uint32_t hmask = testChildren(np, head, sr, tmin, ANYHIT ? FAR_T : best.t);
-                if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
-                    const int mm = (int)meta.z;
-                    bool enter = pregated ? (((gateBits >> mm) & 1ull) != 0) : gate(mm);
-                    if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
-                        chunkMask = 0;
-                        for (int b = 0; b < 8; b++) {
-                            if (STATS) cnt.gateTests++;
-                            if (boxHitDecision(xyz(ld4(S.mdlChunkMin + 8 * mm + b)), xyz(ld4(S.mdlChunkMax + 8 * mm + b)), o, d, sr.rd, rdFinite)) chunkMask |= 1u << b;
-                        }
-                        enter = chunkMask != 0;
-                    }
-                    if (!enter) hmask = 0;
-                }
-                uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
-                if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
-                if (hits != 0) {   // keep the siblings that are still waiting
-                    stk.base[sp * kBlockThreads] = base;
-                    stk.mask[sp * kBlockThreads] = imask | (hits << 8);
-                    sp++;
-                }
-                base = meta.x;
-                imask = nodeImask;
-                hits = permuteOctants(hmask & nodeImask, oct);
-                uint32_t pend = permuteOctants(hmask & nodeLmask, oct);
-                while (pend != 0) {             // queue the leaves front to back
-                    const uint32_t lc = (uint32_t)__builtin_ctz(pend) ^ oct;
-                    pend &= pend - 1;
-                    const uint32_t start = lc == 0 ? ra.x : lc == 1 ? ra.y : lc == 2 ? ra.z : lc == 3 ? ra.w : lc == 4 ? rb.x : lc == 5 ? rb.y : lc == 6 ? rb.z : rb.w;
-                    leafQ[((qhead + queued) & (uint32_t)(kLeafQueue - 1)) * kBlockThreads] = start | (chunkMask << 24);
-                    queued++;
-                }
-                timerA.stop(stk, 0);
-            }
-        } else {
-            // ---- one triangle for every lane that has one
-            if (haveTriangles) {
-                SectionTimer<STATS> timerB;
-                if (cursor == kNoTriangle) {    // oldest queued leaf first
-                    const uint32_t e = leafQ[qhead * kBlockThreads];
-                    cursor = e & 0xFFFFFFu; cursorChunks = e >> 24;
-                    qhead = (qhead + 1u) & (uint32_t)(kLeafQueue - 1);
-                    queued--;
-                }
-                // two records per turn (the second is only used if the leaf goes on; the array ends with spare records)
-                const F4* tp = S.tris + (size_t)cursor * 3;
-                const f4_t A0 = ld4(tp), B0 = ld4(tp + 1), C0 = ld4(tp + 2), A1 = ld4(tp + 3), B1 = ld4(tp + 4), C1 = ld4(tp + 5);
-                auto testTriangle = [&](f4_t A, f4_t B, f4_t C) {
-                const uint32_t idw = fbits(A.w);
-                if (STATS) cnt.triTests++;
-                // Moeller-Trumbore exactly as the reference evaluates it (edges were subtracted on the host)
-                V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
-                V3 pvec = cross(d, e2);
-                float det = dot(e1, pvec);
-                // the reference compares against the double literal -0.01; -0.01f is the smallest float that passes
-                bool rejected = (cull && det >= -0.01f) || (fabsf(det) <= 0);
-                if (meshMode == kMeshEightBoxes) rejected = rejected || (idw & kTriChunkDropped) || !((cursorChunks >> ((idw >> kTriChunkShift) & 7u)) & 1u);
-                if (!rejected) {
-                    float invDet = 1 / det;
-                    V3 tvec = o - v0;
-                    float u = dot(tvec, pvec) * invDet;
-                    if (!(u < 0 || u > 1)) {
-                        V3 qvec = cross(tvec, e1);
-                        float v = dot(d, qvec) * invDet;
-                        if (!(v < 0 || u + v > 1)) {
-                            float t = dot(e2, qvec) * invDet;
-                            const int id = (int)(idw & kTriIdMask), mm = (int)fbits(B.w);
-                            const bool inRange = !positiveOnly || t > 0;      // Model.cpp:287 vs :327
-                            if (ANYHIT) {
-                                if (t < FAR_T && inRange) { found = true; }
-                            } else {
-                                // an exact tie goes to the triangle the reference's loops meet first: lower model, then lower index
-                                const bool earlier = best.kind == KIND_MODEL && (mm < best.idx || (mm == best.idx && id < best.tri));
-                                if (inRange && (t < best.t || (t == best.t && earlier))) {
-                                    best.t = t; best.kind = KIND_MODEL; best.idx = mm; best.tri = id; best.u = u; best.v = v;
-                                }
-                            }
-                        }
-                    }
-                }
-                };
-                testTriangle(A0, B0, C0);
-                uint32_t idw = fbits(A0.w);
-                if (!(idw & kTriLast) && !(ANYHIT && found)) { testTriangle(A1, B1, C1); idw = fbits(A1.w); cursor++; }
-                cursor = (idw & kTriLast) ? kNoTriangle : cursor + 1u;
-                timerB.stop(stk, 1);
-                if (ANYHIT && found) break;
-            }
-        }
-    }
-    timerWhole.stop(stk, 3);
-    return ANYHIT ? found : false;
-}
-
-
-// The same trace for a wave in which eight consecutive lanes (a group) hold the same ray: the group visits one node at a
-// time with one child box per lane, and one leaf at a time with one triangle per lane.  All per-ray state is identical in
-// the eight lanes of a group; groups diverge from each other as lanes do in traceModels.  A single ray finishes sooner
-// this way (a node visit is ~100 instead of ~230 instructions, a leaf one step instead of up to eight), which is what
-// the handful of pixels that decide the length of a frame need; the arithmetic per box and per triangle is the same.
-template <bool ANYHIT, bool STATS>
-RT_DEV bool traceModelsWide(const DevScene& S, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, Closest& best, StackRef stk, Counters& cnt) {
-    if (S.forestRoot == kNoRoot) return false;
-    SectionTimer<STATS> timerWhole;
-    const uint32_t lane = threadIdx.x & 63u, sub = lane & 7u, slot = lane >> 3;
-    const int nMdl = S.nMdl;
-    const bool positiveOnly = meshMode != kMeshNoBox;
-    const float tmin = positiveOnly ? 0.0f : -__builtin_inff();
-    const SlabRay sr = makeSlabRay(o, d);
-    const uint32_t oct = sr.oct;
-    const bool rdFinite = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
-    float bt = best.t;                            // best hit so far: (t, model, triangle), barycentrics
-    int bkind = best.kind, bmm = best.idx, bid = best.tri;
-    float bu = best.u, bv = best.v;
-
-    auto groupBits = [&](bool flag) -> uint32_t { return (uint32_t)(__ballot(flag) >> (8u * slot)) & 0xffu; };
-    auto gate = [&](int mm) -> bool {
-        if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) return false;
-        if (meshMode == kMeshWholeBox) {
-            return boxHitDecision(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), o, d, sr.rd, rdFinite);
-        }
-        return true;
-    };
-
-    // up-front gates, eight models at a time (one per lane)
-    const bool pregated = nMdl <= kPregatedModels;
-    unsigned long long gateBits = 0;
-    if (pregated) {
-        for (int j0 = 0; j0 < nMdl; j0 += 8) {
-            const int j = j0 + (int)sub;
-            bool pass = false;
-            if (j < nMdl && tightBoxHit(xyz(ld4(S.mdlTightMin + j)), xyz(ld4(S.mdlTightMax + j)), sr, tmin, ANYHIT ? FAR_T : bt)) {
-                pass = gate(j);
-                if (STATS && meshMode == kMeshWholeBox) cnt.gateTests++;
-            }
-            gateBits |= (unsigned long long)groupBits(pass) << j0;
-        }
-        if (gateBits == 0) { timerWhole.stop(stk, 3); return false; }
-    }
-
-    uint32_t base = S.forestRoot, imask = 0, hits = 1, chunkMask = 0xffu;
-    int sp = 0;
-    uint32_t* stkBase = stk.base - sub;           // the group keeps its stack in the column of its first lane
-    uint32_t* stkMask = stk.mask - sub;
-    bool found = false;
-
-    for (;;) {
-        // ---- one node visit
-        if (hits == 0) {
-            if (sp == 0) break;
-            sp--;
-            base = stkBase[sp * kBlockThreads];
-            const uint32_t e = stkMask[sp * kBlockThreads];
-            imask = e & 0xffu; hits = e >> 8;
-        }
-        SectionTimer<STATS> timerA;
-        const uint32_t k = __builtin_ctz(hits);
-        hits &= hits - 1;
-        const uint32_t c = k ^ oct;
-        const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
-        const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
-        const u4_t head = *reinterpret_cast<const u4_t*>(np), meta = *reinterpret_cast<const u4_t*>(np + 1);
-        bool myHit;
-        {   // this lane's child: slot `sub` of the node
-            const uint32_t* planes = reinterpret_cast<const uint32_t*>(np + 2);
-            const uint32_t sh8 = 8u * (sub & 3u), dw = sub >> 2;
-            const float lx = (float)((planes[0 + dw] >> sh8) & 0xffu), hx = (float)((planes[2 + dw] >> sh8) & 0xffu);
-            const float ly = (float)((planes[4 + dw] >> sh8) & 0xffu), hy = (float)((planes[6 + dw] >> sh8) & 0xffu);
-            const float lz = (float)((planes[8 + dw] >> sh8) & 0xffu), hz = (float)((planes[10 + dw] >> sh8) & 0xffu);
-            const float sx = ubits((head.w & 0xffu) << 23) * sr.rd.x, sy = ubits(((head.w >> 8) & 0xffu) << 23) * sr.rd.y,
-                        sz = ubits(((head.w >> 16) & 0xffu) << 23) * sr.rd.z;
-            const float bx = __builtin_fmaf(ubits(head.x), sr.rd.x, -sr.ord.x), by = __builtin_fmaf(ubits(head.y), sr.rd.y, -sr.ord.y),
-                        bz = __builtin_fmaf(ubits(head.z), sr.rd.z, -sr.ord.z);
-            const float ax = __builtin_fmaf(lx, sx, bx), cx = __builtin_fmaf(hx, sx, bx);
-            const float ay = __builtin_fmaf(ly, sy, by), cy = __builtin_fmaf(hy, sy, by);
-            const float az = __builtin_fmaf(lz, sz, bz), cz = __builtin_fmaf(hz, sz, bz);
-            const float tn = fmaxf(fmaxf(fminf(ax, cx), fminf(ay, cy)), fmaxf(fminf(az, cz), tmin));
-            const float tf = fminf(fminf(fmaxf(ax, cx), fmaxf(ay, cy)), fminf(fmaxf(az, cz), ANYHIT ? FAR_T : bt));
-            myHit = tn <= tf;
-        }
-        uint32_t hmask = groupBits(myHit);
-        const uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
-        if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
-        if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
-            const int mm = (int)meta.z;
-            bool enter = pregated ? (((gateBits >> mm) & 1ull) != 0) : gate(mm);
-            if (STATS && !pregated && meshMode == kMeshWholeBox) cnt.gateTests++;
-            if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: one chunk gate per lane
-                if (STATS) cnt.gateTests += 8;
-                const bool chunkHit = boxHitDecision(xyz(ld4(S.mdlChunkMin + 8 * mm + (int)sub)), xyz(ld4(S.mdlChunkMax + 8 * mm + (int)sub)), o, d, sr.rd, rdFinite);
-                chunkMask = groupBits(chunkHit);
-                enter = chunkMask != 0;
-            }
-            if (!enter) hmask = 0;
-        }
-        if (hits != 0) {   // keep the siblings that are still waiting
-            if (sub == 0) {
-                stkBase[sp * kBlockThreads] = base;
-                stkMask[sp * kBlockThreads] = imask | (hits << 8);
-            }
-            sp++;
-        }
-        base = meta.x;
-        imask = nodeImask;
-        hits = permuteOctants(hmask & nodeImask, oct);
-        uint32_t pend = permuteOctants(hmask & nodeLmask, oct);
-        timerA.stop(stk, 0);
-
-        // ---- the leaves this visit found: one triangle per lane, eight at a time
-        while (pend != 0) {
-            const uint32_t lc = (uint32_t)__builtin_ctz(pend) ^ oct;
-            pend &= pend - 1;
-            const uint32_t start = reinterpret_cast<const uint32_t*>(np)[20 + lc];
-            for (uint32_t chunk = 0;; chunk += 8u) {
-                SectionTimer<STATS> timerB;
-                const F4* tp = S.tris + (size_t)(start + chunk + sub) * 3;
-                const f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
-                const uint32_t idw = fbits(A.w);
-                // lanes past the end of the leaf read the triangles that follow it (or the spare records at the end of the array)
-                const uint32_t lastBits = groupBits((idw & kTriLast) != 0);
-                const bool valid = lastBits == 0 || sub <= (uint32_t)__builtin_ctz(lastBits);
-                if (STATS) cnt.triTests += lastBits == 0 ? 8u : (uint32_t)__builtin_ctz(lastBits) + 1u;
-                bool cand = false;
-                float t = 0, u = 0, v = 0;
-                int id = 0, mm = 0;
-                if (valid) {
-                    // Moeller-Trumbore exactly as the reference evaluates it (edges were subtracted on the host)
-                    V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
-                    V3 pvec = cross(d, e2);
-                    float det = dot(e1, pvec);
-                    bool rejected = (cull && det >= -0.01f) || (fabsf(det) <= 0);
-                    if (meshMode == kMeshEightBoxes) rejected = rejected || (idw & kTriChunkDropped) || !((chunkMask >> ((idw >> kTriChunkShift) & 7u)) & 1u);
-                    if (!rejected) {
-                        float invDet = 1 / det;
-                        V3 tvec = o - v0;
-                        u = dot(tvec, pvec) * invDet;
-                        if (!(u < 0 || u > 1)) {
-                            V3 qvec = cross(tvec, e1);
-                            v = dot(d, qvec) * invDet;
-                            if (!(v < 0 || u + v > 1)) {
-                                t = dot(e2, qvec) * invDet;
-                                id = (int)(idw & kTriIdMask); mm = (int)fbits(B.w);
-                                const bool inRange = !positiveOnly || t > 0;      // Model.cpp:287 vs :327
-                                if (ANYHIT) cand = t < FAR_T && inRange;
-                                else {
-                                    const bool earlier = bkind == KIND_MODEL && (mm < bmm || (mm == bmm && id < bid));
-                                    cand = inRange && (t < bt || (t == bt && earlier));
-                                }
-                            }
-                        }
-                    }
-                }
-                const uint32_t candBits = groupBits(cand);
-                if (ANYHIT) {
-                    if (candBits) { found = true; pend = 0; hits = 0; sp = 0; }
-                } else if (candBits) {
-                    // the new best = the least (t, model, triangle) among the group's candidates
-                    float rt = cand ? t : __builtin_inff();
-                    int rmm = cand ? mm : 0x7fffffff, rid = cand ? id : 0x7fffffff;
-#pragma unroll
-                    for (int off = 1; off < 8; off <<= 1) {
-                        const float ot = __shfl_xor(rt, off); const int omm = __shfl_xor(rmm, off), oid = __shfl_xor(rid, off);
-                        const bool take = ot < rt || (ot == rt && (omm < rmm || (omm == rmm && oid < rid)));
-                        if (take) { rt = ot; rmm = omm; rid = oid; }
-                    }
-                    const uint32_t winner = slot * 8u + (uint32_t)__builtin_ctz(groupBits(cand && mm == rmm && id == rid));
-                    bt = rt; bkind = KIND_MODEL; bmm = rmm; bid = rid;
-                    bu = __shfl(u, (int)winner); bv = __shfl(v, (int)winner);
-                }
-                timerB.stop(stk, 1);
-                if (lastBits != 0 || (ANYHIT && found)) break;
-            }
-        }
-        if (ANYHIT && found) break;
-    }
-    best.t = bt; best.kind = bkind; best.idx = bmm; best.tri = bid; best.u = bu; best.v = bv;
-    timerWhole.stop(stk, 3);
-    return ANYHIT ? found : false;
-}
-
-// ---------------------------------------------------------------- linear object traces
-
 // Float -> unsigned with the same order (negative values below positive ones), and back.
 RT_DEV uint32_t orderBits(float t) { const uint32_t b = fbits(t); return (b & 0x80000000u) ? ~b : (b | 0x80000000u); }
 RT_DEV float orderFloat(uint32_t m) { return ubits((m & 0x80000000u) ? (m & 0x7fffffffu) : ~m); }
 
-// The same trace with the work of all 64 rays of the wave in two shared pools in LDS: pending children of visited nodes,
-// and pending runs of triangles.  Every turn the wave takes the 64 newest entries of one pool, one per lane, whichever
-// rays they belong to; a lane fetches the ray of its entry from LDS.  With one ray per lane the traversal loop ran with
-// 35 of the 60 lanes that entered it still busy on average (27 in the slowest waves): rays of one 8x8 block need very
-// different numbers of steps.  Here a ray with much work gets the lanes of the rays that are done.
+// Traces the rays of the wave's lanes against every eligible model (kernels.cu:98-128 with Model::hit, Model.cpp:161-357).
+//   ANYHIT = false: closest hit, merged into `best` (which must not hold a model hit yet) with the reference's tie rules:
+//                   strictly nearer than any other kind of object found earlier; among triangles an exact tie goes to
+//                   the lower model index, then the lower triangle index (the one the reference's loops meet first).
+//   ANYHIT = true : returns true if some non-debug model has a triangle with 0 < t < 999.
+// skipDebug: models flagged debug are not candidates (reflection and shadow rays).
+// meshMode (kMesh*): which gates apply and whether a hit needs t > 0 - see Model.cpp:220-356.
+// All 64 lanes must call this together; hasRay says whether the lane brings a ray.
 //
-// All 64 lanes must call this together; hasRay says whether the lane brings a ray.  The nearest hit of ray l is kept in
-// bestKey[l] = orderBits(t) << 32 | key, lowered with a 64-bit LDS atomic minimum; key = the triangle's index in the
-// scene-wide attribute array, which grows with (model, triangle id), so that the minimum implements the reference's tie
-// rule.  The start value holds the distance of the nearest other object with key 0: a triangle must be strictly nearer.
-// bestRec[l] remembers the triangle record of the minimum; when the pools are empty each lane intersects its winning
-// triangle once more to obtain t, u and v (same arithmetic, same values).  An any-hit ray that found something stores
-// 0, and its remaining entries are dropped when they come up.
+// The work of all rays of the wave sits in two shared pools in LDS: pending children of visited nodes, and pending runs
+// of triangles.  Every turn the wave takes the 64 newest entries of one pool, one per lane, whichever rays they belong
+// to; a lane fetches the ray of its entry from LDS.  (With one ray per lane and a private stack, 35 of the 60 lanes that
+// entered the traversal were still busy in an average turn, 27 in the slowest waves: rays of one 8x8 block need very
+// different numbers of steps.  Here a ray with much work gets the lanes of the rays that are done; 47 entries are taken
+// in an average turn.)
+//
+// The nearest hit of ray l is kept in bestKey[l] = orderBits(t) << 32 | key, lowered with a 64-bit LDS atomic minimum;
+// key = the triangle's index in the scene-wide attribute array, which grows with (model, triangle id), so that the
+// minimum implements the tie rule.  The start value holds the distance of the nearest other object with key 0: a triangle
+// must be strictly nearer.  bestRec[l] remembers the triangle record of the minimum; when the pools are empty each lane
+// intersects its winning triangle once more to obtain t, u and v (same arithmetic, same values).  An any-hit ray that
+// found something stores 0, and its remaining entries are dropped when they come up.
 //
 // Entries of one ray can be taken in the same turn, so subtrees are entered that a strictly front-to-back traversal
-// would have pruned; what is visited beyond that never changes the result.  Newest-first order keeps that small: the
-// top of the pool are the children just found, nearest child first.
+// would have pruned (6 % more box tests, 10 % more triangle tests on the 1080p benchmark scene); what is visited beyond
+// need never changes the result.  Newest-first order keeps that small: the top of the pool are the children just found,
+// nearest child first.
 // Pool capacity: a lane's node turn takes one entry and adds at most two (remaining siblings, new children), so a full
-// turn needs 64 free entries; with fewer, single lanes take turns (depth-first on the newest entry, which needs at most
-// one more entry per tree level) until there is room again.  A node turn adds at most eight triangle runs per lane, and
-// is only taken with at most 64 runs pending.
+// turn needs 64 free entries; with fewer than 88, single lanes take turns (depth-first on the newest entry, which needs
+// at most one more entry per tree level) until there is room again.  A node turn adds at most eight triangle runs per
+// lane, and is only taken with fewer than 40 runs pending.
 template <bool ANYHIT, bool STATS>
-RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, Closest& best, StackRef stk, Counters& cnt) {
+RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, Closest& best, WaveLds stk, Counters& cnt) {
     if (S.forestRoot == kNoRoot) return false;
     SectionTimer<STATS> timerWhole;
     const uint32_t lane = threadIdx.x & 63u;
@@ -710,7 +344,8 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
     const float tmin = positiveOnly ? 0.0f : -__builtin_inff();
     const bool pregated = nMdl <= kPregatedModels;
 
-    // Exact gate of model mm for the ray (ro, rd); see traceModels.
+    // Is model mm a candidate for the ray at all: not hidden from this ray type, and (whole-box mode) through the
+    // reference's exact bounding-box gate.
     auto gate = [&](int mm, V3 ro, V3 rdir, V3 rrd, bool fin) -> bool {
         if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) return false;
         if (meshMode == kMeshWholeBox) {
@@ -722,6 +357,9 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
 
     const float startT = ANYHIT ? FAR_T : best.t;
     const unsigned long long init = (unsigned long long)orderBits(startT) << 32;
+    // Small scenes: every lane evaluates the gates of its own ray up front, all lanes with the same trip count (the exact
+    // gate would otherwise be met by single lanes at model roots).  The cheap conservative test of the triangles' own box
+    // comes first; the order does not change the result.  Larger scenes evaluate a gate when an entry reaches a model root.
     unsigned long long gateBits = 0;
     if (hasRay && pregated) {
         SectionTimer<STATS> timerG;
@@ -935,6 +573,8 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
 
 
 
+// ---------------------------------------------------------------- linear object traces
+
 // kernels.cu:67-96 over the three analytic object tables, closest hit.  skipDebug* mirror the ray types the
 // reference uses for each table at this level.
 RT_DEV void traceAnalytic(const DevScene& S, V3 o, V3 d, bool skipDebugSpheres, bool tracePlanes, bool skipDebugPlanes,
@@ -1069,138 +709,12 @@ RT_DEV int renormCount(int kind, bool planesRun, bool boxesRun, bool modelsRun) 
     return 1 + (planesRun ? 1 : 0) + afterPlanes;   // sphere
 }
 
-// Hard-shadow test of the primary level: spheres, boxes, models (kernels.cu:268-277); one ray.
-// One camera sample: kernels.cu:224-318 with the reflection chain kernels.cu:130-222 unrolled into levels.
-template <bool STATS, bool WIDE>
-RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, V3 o, V3 d, int px, int py, StackRef stk, Counters& cnt, Closest& primaryOut) {
-    const V3 lightPos = mk(S.lightPos), lightCol = mk(S.lightCol), eye = mk(P.camPos), background = mk(P.background);
-    const bool reflections = (P.flags & kCfgReflections) != 0, reflectPlanes = (P.flags & kCfgReflectPlanes) != 0;
-    const bool boxesRun = (P.flags & kCfgRenderBoxes) != 0, modelsRun = (P.flags & kCfgRenderModels) != 0;
-    const bool modelsVisible = modelsRun && (P.flags & kCfgModelsVisible) != 0;
-    const bool hardShadows = (P.flags & kCfgHardShadows) != 0, cull = (P.flags & kCfgCull) != 0;
-
-    // per level: own colour, how the deeper colour is added, and whether the level is in shadow
-    V3 lvl0 = background, lvl1 = background, lvl2 = background, lvl3 = background;
-    float str0 = 0, str1 = 0, str2 = 0;
-    bool add0 = false, add1 = false, add2 = false, sh0 = false, sh1 = false, sh2 = false, sh3 = false;
-    float softFactor = 1.0f; bool useSoft = false;
-    int deepest = 0;
-
-    V3 ro = o, rdir = d;
-#pragma unroll 1
-    for (int level = 0; level < 4; level++) {
-        deepest = level;
-        cnt.rays++;
-        Closest h; h.t = FAR_T; h.kind = KIND_NONE; h.idx = -1; h.tri = -1; h.u = 0; h.v = 0;
-        const bool planesRun = (level == 0) || reflectPlanes;
-        { SectionTimer<STATS> tm; traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h); tm.stop(stk, 4); }
-        if (modelsVisible) {
-            // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
-            if (WIDE) traceModelsWide<false, STATS>(S, ro, rdir, cull, (level & 1) != 0, P.meshMode, h, stk, cnt);
-            else traceModels<false, STATS>(S, ro, rdir, cull, (level & 1) != 0, P.meshMode, h, stk, cnt);
-        }
-        if (level == 0) primaryOut = h;
-        V3 colour = background;
-        bool next = false;
-        if (h.kind != KIND_NONE) {
-            SectionTimer<STATS> tmShade;
-            Surface s = resolveSurface<STATS>(S, ro, rdir, h, renormCount(h.kind, planesRun, boxesRun, modelsRun), cnt);
-            const bool isDebug = (s.mat.flags & 1u) != 0;
-            if (level == 0 && isDebug) {
-                colour = s.mat.ka;                                          // kernels.cu:309-312
-            } else {
-                V3 nLight = (level == 0 && h.kind == KIND_BOX) ? s.normal : normalise(s.normal);   // kernels.cu:240-245
-                colour = lighting(s.mat, lightPos, lightCol, s.point, eye, nLight, P, px, py);
-                tmShade.stop(stk, 5);
-                V3 biased = s.point + s.normal * P.shadowBias;
-                V3 toLight = normalise(lightPos - s.point);
-                bool wantNext;
-                if (level == 0) wantNext = reflections && s.mat.type == 1u && !(h.kind == KIND_PLANE && !reflectPlanes);
-                else wantNext = reflections && s.mat.type == 1u && (1 < P.maxDepth) && level < 3;
-                float strength = 0; bool add = false;
-                if (wantNext) {
-                    if (h.kind == KIND_PLANE) { strength = P.planeStrength; add = true; }
-                    else if (h.kind == KIND_SPHERE) { strength = P.sphereStrength; add = true; }
-                    else if (h.kind == KIND_MODEL) { strength = P.modelStrength; add = true; }
-                    else if (h.kind == KIND_BOX && level == 0) { strength = P.boxStrength; add = true; }   // kernels.cu:259
-                }
-                bool shadowed = false;
-                if (level == 0) {
-                    // Shadow rays of the primary hit, one loop so that the any-hit mesh traversal is instantiated once:
-                    // the hard shadow ray towards the light (kernels.cu:268-277, stops at the first occluder kind), then
-                    // the soft shadow samples (kernels.cu:279-307, every occluder kind counts separately).
-                    const int hardRays = hardShadows ? 1 : 0;
-                    const bool soft = (P.flags & kCfgSoftShadows) != 0;
-                    const int shadowRays = hardRays + (soft ? P.softNum : 0);
-                    int hitsCount = 0;
-#pragma unroll 1
-                    for (int q = 0; q < shadowRays; q++) {
-                        const bool hard = q < hardRays;
-                        V3 sd = toLight;
-                        if (!hard) {
-                            V3 ps = lightSampleOffset(sampleSeed(px, py, q - hardRays), P.softRadius);
-                            V3 lightPoint = lightPos + ps;
-                            sd = normalise(lightPoint - s.point);
-                        }
-                        cnt.rays++;
-                        SectionTimer<STATS> tmSh;
-                        const bool bySphere = shadowSpheres(S, biased, sd);
-                        const bool byBox = (hard && bySphere) ? false : shadowBoxes(S, biased, sd);
-                        tmSh.stop(stk, 6);
-                        bool byModel = false;
-                        if ((P.flags & kCfgModelsVisible) && !(hard && (bySphere || byBox))) {   // the shadow traces ignore renderModels (kernels.cu:304)
-                            Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
-                            if (WIDE) byModel = traceModelsWide<true, STATS>(S, biased, sd, cull, true, P.meshMode, dummy, stk, cnt);
-                            else byModel = traceModels<true, STATS>(S, biased, sd, cull, true, P.meshMode, dummy, stk, cnt);
-                        }
-                        if (hard) shadowed = bySphere || byBox || byModel;
-                        else hitsCount += (bySphere ? 1 : 0) + (byBox ? 1 : 0) + (byModel ? 1 : 0);
-                    }
-                    if (soft) {
-                        softFactor = 1 - ((float)hitsCount / (float)P.softNum);
-                        useSoft = true;
-                    }
-                } else if (hardShadows) {
-                    cnt.rays++;
-                    shadowed = shadowSpheres(S, biased, toLight);                                  // kernels.cu:142, 164, 214
-                }
-                if (level == 0) { str0 = strength; add0 = add; sh0 = shadowed; }
-                else if (level == 1) { str1 = strength; add1 = add; sh1 = shadowed; }
-                else if (level == 2) { str2 = strength; add2 = add; sh2 = shadowed; }
-                else { sh3 = shadowed; }
-                if (wantNext) {
-                    next = true;
-                    V3 r = normalise(reflect(rdir, s.normal));
-                    ro = biased;
-                    rdir = r;
-                }
-            }
-        }
-        if (level == 0) lvl0 = colour; else if (level == 1) lvl1 = colour; else if (level == 2) lvl2 = colour; else lvl3 = colour;
-        if (!next) break;
-    }
-
-    // fold the levels back together in the reference's order of operations
-    V3 c3 = lvl3;
-    if (sh3) c3 = c3 * P.shadowIntensity;                               // kernels.cu:140-144
-    V3 c2 = lvl2;
-    if (sh2) c2 = c2 * P.shadowIntensity;                               // kernels.cu:162-166 (before the add)
-    if (deepest >= 3 && add2) c2 = c2 + c3 * str2;                      // kernels.cu:168-180
-    V3 c1 = lvl1;
-    if (deepest >= 2 && add1) c1 = c1 + c2 * str1;                      // kernels.cu:198-210
-    if (sh1) c1 = c1 * P.shadowIntensity;                               // kernels.cu:212-216 (after the add)
-    V3 c0 = lvl0;
-    if (deepest >= 1 && add0) c0 = c0 + c1 * str0;                      // kernels.cu:248-266
-    if (sh0) c0 = c0 * P.shadowIntensity;                               // kernels.cu:268-277
-    if (useSoft) c0 = c0 * softFactor;                                  // kernels.cu:306
-    return c0;
-}
-
-// castSample for the shared-pool mesh trace: the same sequence of rays, with every mesh trace in wave-uniform control flow
-// (all 64 lanes call tracePool; a lane without a ray at that point - outside the frame, chain ended, nothing to shade -
-// passes hasRay = false and lends its lane to the others).  `live`: the lane has a camera sample at all.
+// One camera sample: kernels.cu:224-318 with the reflection chain kernels.cu:130-222 unrolled into four levels (primary
+// ray, then up to three reflections).  Every mesh trace sits in wave-uniform control flow: all 64 lanes call tracePool,
+// and a lane without a ray at that point - outside the frame, chain ended, nothing to shade - passes hasRay = false and
+// lends its lane to the others.  `live`: the lane has a camera sample at all.
 template <bool STATS>
-RT_DEV V3 castSamplePool(const DevScene& S, const FrameParams& P, bool live, V3 o, V3 d, int px, int py, StackRef stk, Counters& cnt, Closest& primaryOut) {
+RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V3 d, int px, int py, WaveLds stk, Counters& cnt, Closest& primaryOut) {
     const V3 lightPos = mk(S.lightPos), lightCol = mk(S.lightCol), eye = mk(P.camPos), background = mk(P.background);
     const bool reflections = (P.flags & kCfgReflections) != 0, reflectPlanes = (P.flags & kCfgReflectPlanes) != 0;
     const bool boxesRun = (P.flags & kCfgRenderBoxes) != 0, modelsRun = (P.flags & kCfgRenderModels) != 0;
@@ -1354,29 +868,27 @@ constexpr int kWavesPerTile = kWavesPerTileSide * kWavesPerTileSide;
 // Bits 0,2,4 of v -> bits 0,1,2 (one coordinate of a Z-order index).
 RT_DEV uint32_t evenBits3(uint32_t v) { return (v & 1u) | ((v >> 1) & 2u) | ((v >> 2) & 4u); }
 
-// WIDE = false: one wave per 8x8 pixel block, one lane per pixel.  WIDE = true: the waves listed in fb.extraMap, each
-// rendering one pixel row of one of the frame's heaviest blocks with eight lanes per ray.
-template <bool STATS, bool WIDE, bool POOL>
+// SPLIT = false: one wave per 8x8 pixel block, one lane per pixel.  SPLIT = true: the waves listed in fb.extraMap, each
+// rendering one pixel row of one of the frame's heaviest blocks: eight lanes bring a pixel, the other 56 only help with
+// the mesh traversal.
+template <bool STATS, bool SPLIT>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3))) void renderKernel(DevScene S, FrameParams P, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
                                                     float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
                                                     unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
                                                     uint32_t* __restrict__ tileCost, BlockFeedback fb) {
     const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
     const unsigned long long cyclesStart = tileCost ? __builtin_readcyclecounter() : 0ull;
-    if (!WIDE && fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
-    // per-lane traversal state (one ray per lane, eight lanes per ray), or the shared pools of tracePool
-    constexpr int kLaneStateWords = POOL ? 1 : kMaxOctreeDepth * kBlockThreads;
-    __shared__ uint32_t stackBase[kLaneStateWords];
-    __shared__ uint32_t stackMask[kLaneStateWords];
-    __shared__ uint32_t leafQueue[POOL ? 1 : kLeafQueue * kBlockThreads];
-    __shared__ f4_t poolRays[POOL ? 3 * kBlockThreads : 1];
-    __shared__ unsigned long long poolBest[POOL ? kBlockThreads : 1];
-    __shared__ uint32_t poolRec[POOL ? kBlockThreads : 1];
-    __shared__ unsigned long long poolNodes[POOL ? kNodePool : 1];
-    __shared__ unsigned long long poolTris[POOL ? kTriPool : 1];
+    if (!SPLIT && fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
+    // 12416 bytes per wave: twelve waves per CU (three per SIMD) fit the 160 KB of LDS.  Measured: at 12928 bytes fewer
+    // waves are resident and the frame takes 7 % longer.
+    __shared__ f4_t poolRays[3 * kBlockThreads];
+    __shared__ unsigned long long poolBest[kBlockThreads];
+    __shared__ uint32_t poolRec[kBlockThreads];
+    __shared__ unsigned long long poolNodes[kNodePool];
+    __shared__ unsigned long long poolTris[kTriPool];
     __shared__ unsigned long long profile[16];  // section accumulators of the instrumented kernel: (cycles, executions) x 8
     const uint32_t lane = threadIdx.x;
-    StackRef stk; stk.base = stackBase + lane; stk.mask = stackMask + lane; stk.leaves = leafQueue + lane; stk.prof = profile;
+    WaveLds stk; stk.prof = profile;
     stk.rayO = poolRays; stk.rayD = poolRays + kBlockThreads; stk.rayR = poolRays + 2 * kBlockThreads; stk.bestKey = poolBest; stk.bestRec = poolRec; stk.nodePool = poolNodes; stk.triPool = poolTris;
     if (STATS) { if (lane < 16) profile[lane] = 0; __syncthreads(); }
 
@@ -1384,7 +896,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     // tile sequence: the 64 waves of a tile share one L2, and every XCD gets the same mix of cheap and expensive tiles.
     uint32_t localTile, inTile, sub = 0;
     bool retire = false;
-    if (WIDE) {
+    if (SPLIT) {
         const uint32_t count = *fb.extraCount;
         if (blockIdx.x < (count < (uint32_t)kMaxExtraWaves ? count : (uint32_t)kMaxExtraWaves)) {
             const uint32_t e = fb.extraMap[blockIdx.x];
@@ -1416,21 +928,18 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
         }
         return;
     }
-    constexpr bool splitWave = WIDE;
     const uint32_t tile = localTile * (uint32_t)P.world + (uint32_t)P.rank;
     const uint32_t tileX = tile % (uint32_t)P.tilesX, tileY = tile / (uint32_t)P.tilesX;
     // the waves of a tile walk it in Z order (neighbours in time are neighbours on screen).  A regular wave renders the whole
-    // 8x8 block, lane l = pixel (l & 7, l >> 3); a split wave renders row `sub` of the block with eight lanes per pixel.
+    // 8x8 block, lane l = pixel (l & 7, l >> 3); a split wave renders row `sub` of the block with its first eight lanes.
     const uint32_t bx = evenBits3(inTile) * 8u, by = evenBits3(inTile >> 1) * 8u;
-    // (with the shared-pool trace a split wave has eight live lanes, one per pixel of the row, and 56 lanes that only help)
-    constexpr bool replicated = WIDE && !POOL;    // eight lanes compute the same pixel
-    const bool rowLane = !(WIDE && POOL) || lane < 8u;
-    const uint32_t lx = bx + (replicated ? (lane >> 3) : (lane & 7u)), ly = by + (splitWave ? sub : (lane >> 3));
+    const bool pixelLane = !SPLIT || lane < 8u;
+    const uint32_t lx = bx + (lane & 7u), ly = by + (SPLIT ? sub : (lane >> 3));
     const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
 
     Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0;
-    const bool inFrame = rowLane && x < P.width && y < P.height;
-    if (POOL || inFrame) {      // the shared-pool trace needs all 64 lanes, also those outside the frame
+    const bool inFrame = pixelLane && x < P.width && y < P.height;
+    {      // all 64 lanes, also those without a pixel: the mesh trace is a wave-wide operation
         const V3 camPos = mk(P.camPos);
         V3 col;
         Closest primary; primary.t = FAR_T; primary.kind = KIND_NONE; primary.idx = -1; primary.tri = -1; primary.u = 0; primary.v = 0;
@@ -1445,14 +954,12 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
             const float offX = antiAlias ? ((sIdx & 2) ? 0.75f : 0.25f) : 0.5f, offY = antiAlias ? ((sIdx & 1) ? 0.75f : 0.25f) : 0.5f;
             V3 p = rasterToCameraSpace(P, (float)x + offX, (float)y + offY);
             Closest ph;
-            V3 c;
-            if (POOL) c = castSamplePool<STATS>(S, P, inFrame, camPos, normalise(p), x, y, stk, cnt, ph);
-            else c = castSample<STATS, WIDE>(S, P, camPos, normalise(p), x, y, stk, cnt, ph);
+            V3 c = castSample<STATS>(S, P, inFrame, camPos, normalise(p), x, y, stk, cnt, ph);
             if (sIdx == 0) primary = ph;
             total = antiAlias ? total + c : c;
         }
         col = antiAlias ? total / 4.0f : total;
-        if (inFrame && (!replicated || (lane & 7u) == 0u)) {      // the eight lanes of a split wave's pixel hold the same result
+        if (inFrame) {
             size_t pix;
             if (P.compactOutput) pix = (size_t)localTile * (RT_TILE_PX * RT_TILE_PX) + (size_t)ly * RT_TILE_PX + lx;
             else pix = (size_t)y * (size_t)P.width + (size_t)x;
@@ -1470,8 +977,6 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
             }
         }
     }
-    if (replicated && (lane & 7u) != 0u) { cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; }
-
     if (STATS && waveClocks && lane == 0) {      // diagnostic: when this wave started and finished, and its section sums
         unsigned long long* rec = waveClocks + kWaveRecordWords * (size_t)blockIdx.x;
         rec[0] = clockStart;
@@ -1481,10 +986,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     if (tileCost && lane == 0) {
         const unsigned long long spent = __builtin_readcyclecounter() - cyclesStart;
         // a split wave stands for the whole block: count it as what one regular wave would have needed.  The factor is a
-        // little below the measured speed-up (2.7) so that a block never looks heavier split than it was unsplit, which
+        // little below the measured speed-up (1.65) so that a block never looks heavier split than it was unsplit, which
         // would keep a frame that does not profit from splitting in the split state.
         const uint32_t own = (uint32_t)(spent >> 6) + 1u;
-        const uint32_t cost = splitWave ? own * 3u / 2u : own;
+        const uint32_t cost = SPLIT ? own * 3u / 2u : own;
         atomicMax(&tileCost[localTile], cost);   // a tile is as urgent as its slowest wave
         if (fb.blockCost) atomicMax(&fb.blockCost[localTile * (uint32_t)kWavesPerTile + inTile], cost);
     }
@@ -1553,30 +1058,18 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
                         const uint32_t* tileOrder, uint32_t* tileCost, BlockFeedback fb) {
     if (P.ownedTiles <= 0) return hipSuccess;
     dim3 grid(launchGridBlocks(P)), block(kBlockThreads);
-    static const bool pool = !(std::getenv("RT_POOL") && std::atoi(std::getenv("RT_POOL")) == 0);
-    if (pool) {
-        if (stats) hipLaunchKernelGGL((renderKernel<true, false, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
-        else hipLaunchKernelGGL((renderKernel<false, false, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
-    } else {
-        if (stats) hipLaunchKernelGGL((renderKernel<true, false, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
-        else hipLaunchKernelGGL((renderKernel<false, false, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
-    }
+    if (stats) hipLaunchKernelGGL((renderKernel<true, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
+    else hipLaunchKernelGGL((renderKernel<false, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
     return hipGetLastError();
 }
 
-hipError_t launchRenderWide(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
+hipError_t launchRenderSplit(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
                             unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
                             uint32_t* tileCost, BlockFeedback fb) {
     if (P.ownedTiles <= 0 || !P.split) return hipSuccess;
     dim3 grid((unsigned)kMaxExtraWaves), block(kBlockThreads);
-    static const bool pool = !(std::getenv("RT_POOL_SPLIT") && std::atoi(std::getenv("RT_POOL_SPLIT")) == 0);
-    if (pool) {
-        if (stats) hipLaunchKernelGGL((renderKernel<true, true, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
-        else hipLaunchKernelGGL((renderKernel<false, true, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
-        return hipGetLastError();
-    }
-    if (stats) hipLaunchKernelGGL((renderKernel<true, true, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
-    else hipLaunchKernelGGL((renderKernel<false, true, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
+    if (stats) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
+    else hipLaunchKernelGGL((renderKernel<false, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
     return hipGetLastError();
 }
 
@@ -1607,10 +1100,10 @@ __global__ __launch_bounds__(256) void blockStatsKernel(const uint32_t* __restri
 }
 
 // Chooses the cost bin from which blocks are split in the next frame, and hands those blocks to split waves (eight per
-// block, one per pixel row, eight lanes per ray).  Every workgroup derives the same decision from the statistics.
-// Model: a split block finishes kSplitSpeedup times sooner and its eight waves occupy wave slots for 8 / kSplitSpeedup times
-// the block's cost (measured: 2.7 times sooner); the frame takes max(T, maxCost / kSplitSpeedup, 1.25 x (sum of costs +
-// extra occupancy) / slots) - the 1.25 is how far a real frame stays behind perfectly even packing.  T runs over the lower
+// block, one per pixel row).  Every workgroup derives the same decision from the statistics.
+// Model: a split block finishes kSplitGainNum / kSplitGainDen times sooner (measured: 1.65) and its eight waves occupy
+// wave slots for 8 x kSplitGainDen / kSplitGainNum times the block's cost; the frame takes max(T, maxCost x Den / Num,
+// 1.25 x (sum of costs + extra occupancy) / slots) - the 1.25 is how far a real frame stays behind perfectly even packing.  T runs over the lower
 // edges of the top cost bins.  Nothing is split unless the model promises a frame at least 10 % shorter and the frame is
 // clearly limited by its heaviest block: that block alone must take more than 1.6 times the evenly packed frame to start
 // splitting, 1.3 times to carry on (the costs of split blocks are estimates; without the band a frame near the limit
@@ -1687,7 +1180,7 @@ int residentRenderWaves() {
     int device = 0, cus = 0, perCu = 0;
     if (hipGetDevice(&device) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<false, false, true>, kBlockThreads, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<false, false>, kBlockThreads, 0) != hipSuccess) return 0;
     return cus * perCu;
 }
 

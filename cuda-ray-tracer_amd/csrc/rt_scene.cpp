@@ -500,7 +500,7 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err, bool
     out.forestDepth = forestDepth;
     out.params = params;
     out.maxDepth += forestDepth;
-    if (out.maxDepth >= kMaxOctreeDepth) { err = "forest plus octree nesting exceeds the traversal stack"; return false; }
+    if (out.maxDepth >= kMaxOctreeDepth) { err = "forest plus octree nesting exceeds the depth the traversal reserves pool entries for"; return false; }
     // spare triangle records: the split waves read eight consecutive records wherever a leaf starts
     if (!out.tris.empty()) { for (int k = 0; k < 3 * kSpareTriangles; k++) out.tris.push_back(f4(0.0f, 0.0f, 0.0f, 0.0f)); }
     if (out.triangleCount + kSpareTriangles > (int64_t)kMaxTriangleRecords) { err = "too many triangles in the scene (" + std::to_string(kMaxTriangleRecords) + " records at most)"; return false; }
@@ -554,7 +554,7 @@ struct Walker {
 
     // m: model whose octree the node belongs to, -1 above the model roots
     bool node(uint32_t index, int m, const double plo[3], const double phi[3], int depth) {
-        if (depth >= kMaxOctreeDepth) { err = "nesting deeper than the traversal stack"; return false; }
+        if (depth >= kMaxOctreeDepth) { err = "nesting deeper than the traversal reserves pool entries for"; return false; }
         deepest = std::max(deepest, depth + 1);
         if ((size_t)(index + 1) * kNodeFloat4s > flat.nodes.size()) { err = "node index out of range"; return false; }
         const F4* rec = &flat.nodes[(size_t)index * kNodeFloat4s];

@@ -54,7 +54,7 @@ bool flattenScene(const rt_scene_desc& scene, FlatScene& out, std::string& err, 
 // Walks the flattened octrees of `flat` (built from `scene`) and checks the invariants the traversal kernel relies on:
 // the forest reaches every non-empty model's root exactly once; every reachable triangle of every model sits in
 // exactly one leaf below that root, inside the padded box of the slot that holds it and tagged with its model;
-// child boxes nest; internal children are contiguous and in range; no path is deeper than the traversal stack.
+// child boxes nest; internal children are contiguous and in range; no path is deeper than kMaxOctreeDepth.
 bool validateFlatScene(const rt_scene_desc& scene, const FlatScene& flat, std::string& err);
 
 // Packs one material into the three-float4 device form.
