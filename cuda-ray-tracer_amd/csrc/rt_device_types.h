@@ -96,6 +96,7 @@ struct FrameParams {
     int32_t rank, world, tilesX, tilesY, ownedTiles;
     int32_t compactOutput;     // 1: write tile-major into the rank's compact buffer, 0: row-major full frame
     int32_t blockOrder;        // workgroup -> tile mapping: 0 tile by tile, 2 tiles interleaved over the XCDs
+    int32_t nodePoolEntries;   // capacity of the traversal's pool of pending children that a wave may use (96 .. the compiled size; smaller values only serve tests)
     int32_t split;             // 1: the grid starts with kMaxExtraWaves workgroups for split blocks (BlockFeedback::extraMap)
     float camPos[3], camUp[3], camRight[3], camDir[3], fovFactor;
     // SceneConfig

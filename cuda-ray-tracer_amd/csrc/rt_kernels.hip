@@ -335,7 +335,7 @@ RT_DEV float orderFloat(uint32_t m) { return ubits((m & 0x80000000u) ? (m & 0x7f
 // at most one more entry per tree level) until there is room again.  A node turn adds at most eight triangle runs per
 // lane, and is only taken with fewer than 40 runs pending.
 template <bool ANYHIT, bool STATS>
-RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, Closest& best, WaveLds stk, Counters& cnt) {
+RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t nodeCapacity, Closest& best, WaveLds stk, Counters& cnt) {
     if (S.forestRoot == kNoRoot) return false;
     SectionTimer<STATS> timerWhole;
     const uint32_t lane = threadIdx.x & 63u;
@@ -393,7 +393,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
         const bool nodeTurn = nodeCount != 0 && triCount < 40u;    // measured: 16 -> +2 %, 32..48 best, 64 -> +2 % frame time
         if (nodeTurn) {
             SectionTimer<STATS> timerA;
-            const uint32_t room = (uint32_t)kNodePool - nodeCount;
+            const uint32_t room = nodeCapacity - nodeCount;
             const uint32_t width = room >= 88u ? 64u : 1u;       // 64 for the turn + more than one entry per tree level for what may follow
             const uint32_t take = nodeCount < width ? nodeCount : width;
             const bool mine = lane < take;
@@ -720,6 +720,8 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
     const bool boxesRun = (P.flags & kCfgRenderBoxes) != 0, modelsRun = (P.flags & kCfgRenderModels) != 0;
     const bool modelsVisible = modelsRun && (P.flags & kCfgModelsVisible) != 0;
     const bool hardShadows = (P.flags & kCfgHardShadows) != 0, cull = (P.flags & kCfgCull) != 0;
+    // 64 root entries must fit, and a full turn needs 88 free entries
+    const uint32_t nodeCapacity = (P.nodePoolEntries >= 96 && P.nodePoolEntries < kNodePool) ? (uint32_t)P.nodePoolEntries : (uint32_t)kNodePool;
 
     V3 lvl0 = background, lvl1 = background, lvl2 = background, lvl3 = background;
     float str0 = 0, str1 = 0, str2 = 0;
@@ -740,7 +742,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
             SectionTimer<STATS> tm; traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h); tm.stop(stk, 4);
         }
         // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
-        if (modelsVisible) tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, h, stk, cnt);
+        if (modelsVisible) tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, nodeCapacity, h, stk, cnt);
         if (level == 0 && active) primaryOut = h;
         V3 colour = background;
         bool next = false, lit = false, wantNext = false, add = false, shadowed = false;
@@ -799,7 +801,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
                 if (P.flags & kCfgModelsVisible) {   // the shadow traces ignore renderModels (kernels.cu:304)
                     const bool needModel = lit && !(hard && (bySphere || byBox));
                     Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
-                    byModel = tracePool<true, STATS>(S, needModel, biased, sd, cull, true, P.meshMode, dummy, stk, cnt);
+                    byModel = tracePool<true, STATS>(S, needModel, biased, sd, cull, true, P.meshMode, nodeCapacity, dummy, stk, cnt);
                 }
                 if (lit) {
                     if (hard) shadowed = bySphere || byBox || byModel;

@@ -1,6 +1,7 @@
-"""Split waves: the heaviest 8x8 blocks of a frame are rendered in the next frame by eight waves with eight lanes per ray.
-RT_SPLIT_RATIO=0 makes the selection take every block that fits, so that most pixels of these small frames go through
-that path; the frames must not change by a single byte, and hit ids / distances must match the CPU oracle."""
+"""Split waves: the heaviest 8x8 blocks of a frame are rendered in the next frame by eight waves, one per pixel row (eight
+lanes bring a pixel, the other 56 only help with the mesh traversal).  RT_SPLIT_RATIO=0 makes the selection take every
+block that fits, so that most pixels of these small frames go through that path; the frames must not change by a single
+byte, and hit ids / distances must match the CPU oracle."""
 import os
 
 import numpy as np

@@ -1,0 +1,68 @@
+"""The mesh traversal keeps the pending work of a wave's 64 rays in two LDS pools.  When the pool of pending children
+has fewer than 88 free entries, single lanes descend depth-first until there is room again.  The compiled capacity (512)
+is rarely exhausted, so these tests shrink it (RT_NODE_POOL, read when a context is created) until that path carries
+most of the traversal, and require byte-identical frames and oracle parity."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_package
+from parity import assert_parity, compare_frames
+
+load_package()
+from cuda_ray_tracer_amd import binding, scenes  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(params=[96, 160])
+def small_pool_renderer(request):
+    old = os.environ.get("RT_NODE_POOL")
+    os.environ["RT_NODE_POOL"] = str(request.param)
+    r = binding.Renderer(0)
+    yield r
+    r.close()
+    if old is None:
+        os.environ.pop("RT_NODE_POOL", None)
+    else:
+        os.environ["RT_NODE_POOL"] = old
+
+
+@pytest.mark.parametrize("mode", ["default", "eightboxes", "nobox", "deep"])
+def test_small_node_pool_renders_the_same_frame(renderer, small_pool_renderer, oracle, mode):
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.25)
+    kw = {}
+    if mode == "eightboxes":
+        cfg.boundingBox = 0; cfg.eightBoundingBoxes = 1
+    elif mode == "nobox":
+        cfg.boundingBox = 0; cfg.eightBoundingBoxes = 0
+    elif mode == "deep":
+        kw = dict(octree_max_depth=10, octree_leaf_triangles=1)     # tall trees: many entries per ray
+    w, h = 320, 180
+    built = scenes.build_scene(spec, **kw)
+    for r in (renderer, small_pool_renderer):
+        r.upload(built.desc)
+        r.set_state(built.camera, cfg)
+    plain, st0 = renderer.render(w, h)
+    rgb, st = small_pool_renderer.render(w, h)
+    assert np.array_equal(rgb, plain)
+    assert st.rays == st0.rays
+    g_rgb, g_ids, g_t, st = small_pool_renderer.render_ids(w, h)
+    o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built.desc, built.camera, cfg, w, h, threads=16)
+    stats = compare_frames(g_rgb, g_ids, g_t, o_rgb, o_ids, o_t, None)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+
+
+def test_full_size_frame_with_small_pool_matches(renderer, small_pool_renderer):
+    """The 1080p benchmark frame, full-detail meshes: a small pool changes the order of the work, never a pixel."""
+    spec, cfg, w, h = scenes.config_scene(3)
+    built = scenes.build_scene(spec)
+    for r in (renderer, small_pool_renderer):
+        r.upload(built.desc)
+        r.set_state(built.camera, cfg)
+    plain, st0 = renderer.render(w, h)
+    rgb, st = small_pool_renderer.render(w, h)
+    assert np.array_equal(rgb, plain)
+    assert st.rays == st0.rays
