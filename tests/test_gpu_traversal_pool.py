@@ -66,3 +66,27 @@ def test_full_size_frame_with_small_pool_matches(renderer, small_pool_renderer):
     rgb, st = small_pool_renderer.render(w, h)
     assert np.array_equal(rgb, plain)
     assert st.rays == st0.rays
+
+
+@pytest.mark.parametrize("mode", ["whole", "eightboxes"])
+def test_many_models_gates_on_the_fly(renderer, small_pool_renderer, oracle, mode):
+    """More than 64 models: no up-front gate pass, the lane that takes a model-root entry evaluates that model's gates
+    (and in the eight-box mode its chunk gates) for the entry's ray."""
+    spec, cfg, _, _ = scenes.config_scene(5, detail=0.15)
+    if mode == "eightboxes":
+        cfg.boundingBox = 0; cfg.eightBoundingBoxes = 1
+    w, h = 320, 180
+    built = scenes.build_scene(spec)
+    assert built.desc.modelCount > 64
+    for r in (renderer, small_pool_renderer):
+        r.upload(built.desc)
+        r.set_state(built.camera, cfg)
+    plain, st0 = renderer.render(w, h)
+    rgb, st = small_pool_renderer.render(w, h)
+    assert np.array_equal(rgb, plain) and st.rays == st0.rays
+    window = (120, 60, 200, 100)
+    g_rgb, g_ids, g_t, st = renderer.render_ids(w, h)
+    o_rgb, o_ids, o_t, _, _ = oracle.render(built.desc, built.camera, cfg, w, h, window=window, threads=16)
+    stats = compare_frames(g_rgb, g_ids, g_t, o_rgb, o_ids, o_t, window)
+    assert_parity(stats)
+    assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
