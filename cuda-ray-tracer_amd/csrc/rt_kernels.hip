@@ -372,6 +372,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
         timerG.stop(stk, 2);
     }
     const bool enters = hasRay && (!pregated || gateBits != 0);
+    if (__ballot(enters) == 0ull) { timerWhole.stop(stk, 3); return false; }     // no ray of this wave comes near a mesh
     {
         f4_t ro4 = {o.x, o.y, o.z, ubits((uint32_t)gateBits)}, rd4 = {d.x, d.y, d.z, ubits((uint32_t)(gateBits >> 32))};
         const SlabRay own = makeSlabRay(o, d);
