@@ -331,8 +331,9 @@ RT_DEV float orderFloat(uint32_t m) { return ubits((m & 0x80000000u) ? (m & 0x7f
 // need never changes the result.  Newest-first order keeps that small: the top of the pool are the children just found,
 // nearest child first.
 // Pool capacity: a lane's node turn takes one entry and adds at most two (remaining siblings, new children), so a full
-// turn needs 64 free entries; with fewer than 88, single lanes take turns (depth-first on the newest entry, which needs
-// at most one more entry per tree level) until there is room again.  A node turn adds at most eight triangle runs per
+// turn needs 64 free entries; with fewer than 88 free, only as many lanes take entries as leaves 24 in reserve, and at
+// the limit single lanes take turns (depth-first on the newest entry, which needs at most one more entry per tree
+// level) until there is room again.  A node turn adds at most eight triangle runs per
 // lane, and is only taken with fewer than 40 runs pending.
 template <bool ANYHIT, bool STATS>
 RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t nodeCapacity, Closest& best, WaveLds stk, Counters& cnt) {
@@ -395,7 +396,8 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
         if (nodeTurn) {
             SectionTimer<STATS> timerA;
             const uint32_t room = nodeCapacity - nodeCount;
-            const uint32_t width = room >= 88u ? 64u : 1u;       // 64 for the turn + more than one entry per tree level for what may follow
+            // a lane's turn adds at most one entry net; 24 entries stay in reserve for a depth-first descent by single lanes
+            const uint32_t width = room >= 88u ? 64u : (room > 25u ? room - 24u : 1u);
             const uint32_t take = nodeCount < width ? nodeCount : width;
             const bool mine = lane < take;
             if (STATS && lane == 0) { stk.prof[14] += take; stk.prof[15] += 1ull + (64ull << 32); }
