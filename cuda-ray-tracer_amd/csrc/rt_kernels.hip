@@ -211,11 +211,11 @@ template <bool STATS>
 struct SectionTimer {
     unsigned long long t0;
     RT_DEV SectionTimer() : t0(STATS ? __builtin_readcyclecounter() : 0ull) {}
-    RT_DEV void stop(const WaveLds& stk, int slot) {
+    RT_DEV void stop(const WaveLds& lds, int slot) {
         if (STATS) {
             unsigned long long dt = __builtin_readcyclecounter() - t0;
             unsigned long long active = __ballot(1);
-            if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)active) - 1)) { stk.prof[2 * slot] += dt; stk.prof[2 * slot + 1] += 1ull + ((unsigned long long)__builtin_popcountll(active) << 32); }
+            if ((threadIdx.x & 63u) == (unsigned)(__ffsll((long long)active) - 1)) { lds.prof[2 * slot] += dt; lds.prof[2 * slot + 1] += 1ull + ((unsigned long long)__builtin_popcountll(active) << 32); }
         }
     }
 };
@@ -336,7 +336,7 @@ RT_DEV float orderFloat(uint32_t m) { return ubits((m & 0x80000000u) ? (m & 0x7f
 // level) until there is room again.  A node turn adds at most eight triangle runs per
 // lane, and is only taken with fewer than 40 runs pending.
 template <bool ANYHIT, bool STATS>
-RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t nodeCapacity, Closest& best, WaveLds stk, Counters& cnt) {
+RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t nodeCapacity, Closest& best, WaveLds lds, Counters& cnt) {
     if (S.forestRoot == kNoRoot) return false;
     SectionTimer<STATS> timerWhole;
     const uint32_t lane = threadIdx.x & 63u;
@@ -370,23 +370,23 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             if (!tightBoxHit(xyz(ld4(S.mdlTightMin + j)), xyz(ld4(S.mdlTightMax + j)), sr, tmin, startT)) continue;
             if (gate(j, o, d, sr.rd, fin)) gateBits |= 1ull << j;
         }
-        timerG.stop(stk, 2);
+        timerG.stop(lds, 2);
     }
     const bool enters = hasRay && (!pregated || gateBits != 0);
-    if (__ballot(enters) == 0ull) { timerWhole.stop(stk, 3); return false; }     // no ray of this wave comes near a mesh
+    if (__ballot(enters) == 0ull) { timerWhole.stop(lds, 3); return false; }     // no ray of this wave comes near a mesh
     {
         f4_t ro4 = {o.x, o.y, o.z, ubits((uint32_t)gateBits)}, rd4 = {d.x, d.y, d.z, ubits((uint32_t)(gateBits >> 32))};
         const SlabRay own = makeSlabRay(o, d);
         f4_t rr4 = {own.rd.x, own.rd.y, own.rd.z, ubits(own.oct)};
-        stk.rayO[lane] = ro4; stk.rayD[lane] = rd4; stk.rayR[lane] = rr4;
-        stk.bestKey[lane] = init;
+        lds.rayO[lane] = ro4; lds.rayD[lane] = rd4; lds.rayR[lane] = rr4;
+        lds.bestKey[lane] = init;
     }
     // one pseudo entry per ray that resolves to the forest root
     uint32_t nodeCount, triCount = 0;
     {
         const unsigned long long m = __ballot(enters);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (enters) stk.nodePool[rank] = (unsigned long long)S.forestRoot | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
+        if (enters) lds.nodePool[rank] = (unsigned long long)S.forestRoot | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
         nodeCount = (uint32_t)__builtin_popcountll(m);
     }
     __builtin_amdgcn_wave_barrier();
@@ -400,15 +400,15 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             const uint32_t width = room >= 88u ? 64u : (room > 25u ? room - 24u : 1u);
             const uint32_t take = nodeCount < width ? nodeCount : width;
             const bool mine = lane < take;
-            if (STATS && lane == 0) { stk.prof[14] += take; stk.prof[15] += 1ull + (64ull << 32); }
+            if (STATS && lane == 0) { lds.prof[14] += take; lds.prof[15] += 1ull + (64ull << 32); }
             unsigned long long e = 0;
-            if (mine) e = stk.nodePool[nodeCount - 1u - lane];
+            if (mine) e = lds.nodePool[nodeCount - 1u - lane];
             nodeCount -= take;
             const uint32_t base = (uint32_t)e, packed = (uint32_t)(e >> 32);
             const uint32_t imask = packed & 0xffu, hits = (packed >> 8) & 0xffu, owner = (packed >> 16) & 63u;
             uint32_t chunkMask = packed >> 24;
             unsigned long long bk = 0;
-            if (mine) bk = stk.bestKey[owner];
+            if (mine) bk = lds.bestKey[owner];
             const bool alive = mine && !(ANYHIT && bk == 0ull);
             // the siblings that are still waiting go back first, so that the children found now end up on top
             const uint32_t rest = hits & (hits - 1u);
@@ -416,13 +416,13 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 const bool again = alive && rest != 0u;
                 const unsigned long long m = __ballot(again);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (again) stk.nodePool[nodeCount + rank] = (unsigned long long)base | ((unsigned long long)(imask | (rest << 8) | (owner << 16) | (chunkMask << 24)) << 32);
+                if (again) lds.nodePool[nodeCount + rank] = (unsigned long long)base | ((unsigned long long)(imask | (rest << 8) | (owner << 16) | (chunkMask << 24)) << 32);
                 nodeCount += (uint32_t)__builtin_popcountll(m);
             }
             uint32_t childHits = 0, pend = 0, childBase = 0, childImask = 0, oct = 0;
             u4_t ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
             if (alive) {
-                const f4_t ro4 = stk.rayO[owner], rr4 = stk.rayR[owner];
+                const f4_t ro4 = lds.rayO[owner], rr4 = lds.rayR[owner];
                 const V3 ro = xyz(ro4);
                 SlabRay sr;
                 sr.rd = xyz(rr4); sr.ord = mk(ro.x * sr.rd.x, ro.y * sr.rd.y, ro.z * sr.rd.z); sr.oct = fbits(rr4.w);
@@ -435,7 +435,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 uint32_t hmask = testChildren(np, head, sr, tmin, tmax);
                 if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
                     const int mm = (int)meta.z;
-                    const f4_t rd4 = stk.rayD[owner];
+                    const f4_t rd4 = lds.rayD[owner];
                     const V3 rdir = xyz(rd4);
                     const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
                     const unsigned long long bits = (unsigned long long)fbits(ro4.w) | ((unsigned long long)fbits(rd4.w) << 32);
@@ -462,7 +462,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 const bool down = childHits != 0u;
                 const unsigned long long m = __ballot(down);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (down) stk.nodePool[nodeCount + rank] = (unsigned long long)childBase | ((unsigned long long)(childImask | (childHits << 8) | (owner << 16) | (chunkMask << 24)) << 32);
+                if (down) lds.nodePool[nodeCount + rank] = (unsigned long long)childBase | ((unsigned long long)(childImask | (childHits << 8) | (owner << 16) | (chunkMask << 24)) << 32);
                 nodeCount += (uint32_t)__builtin_popcountll(m);
             }
             // leaves, farthest first so that the nearest is the newest
@@ -476,28 +476,28 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                     pend &= ~(1u << k);
                     const uint32_t lc = k ^ oct;
                     const uint32_t start = lc == 0 ? ra.x : lc == 1 ? ra.y : lc == 2 ? ra.z : lc == 3 ? ra.w : lc == 4 ? rb.x : lc == 5 ? rb.y : lc == 6 ? rb.z : rb.w;
-                    stk.triPool[triCount + rank] = (unsigned long long)start | ((unsigned long long)(owner | (chunkMask << 8)) << 32);
+                    lds.triPool[triCount + rank] = (unsigned long long)start | ((unsigned long long)(owner | (chunkMask << 8)) << 32);
                 }
                 triCount += (uint32_t)__builtin_popcountll(m);
             }
-            timerA.stop(stk, 0);
+            timerA.stop(lds, 0);
         } else {
             SectionTimer<STATS> timerB;
             const uint32_t take = triCount < 64u ? triCount : 64u;
             const bool mine = lane < take;
-            if (STATS && lane == 0) { stk.prof[14] += take; stk.prof[15] += 1ull + (64ull << 32); }
+            if (STATS && lane == 0) { lds.prof[14] += take; lds.prof[15] += 1ull + (64ull << 32); }
             unsigned long long e = 0;
-            if (mine) e = stk.triPool[triCount - 1u - lane];
+            if (mine) e = lds.triPool[triCount - 1u - lane];
             triCount -= take;
             const uint32_t first = (uint32_t)e, owner = (uint32_t)(e >> 32) & 63u, chunks = (uint32_t)(e >> 40) & 0xffu;
             unsigned long long bk = 0;
-            if (mine) bk = stk.bestKey[owner];
+            if (mine) bk = lds.bestKey[owner];
             const bool alive = mine && !(ANYHIT && bk == 0ull);
             bool goesOn = false;
             if (alive) {
                 const F4* tp = S.tris + (size_t)first * 3;
                 const f4_t A0 = ld4(tp), B0 = ld4(tp + 1), C0 = ld4(tp + 2), A1 = ld4(tp + 3), B1 = ld4(tp + 4), C1 = ld4(tp + 5);
-                const V3 ro = xyz(stk.rayO[owner]), rdir = xyz(stk.rayD[owner]);
+                const V3 ro = xyz(lds.rayO[owner]), rdir = xyz(lds.rayD[owner]);
                 auto testTriangle = [&](f4_t A, f4_t B, f4_t C, uint32_t record) {
                     const uint32_t idw = fbits(A.w);
                     if (STATS) cnt.triTests++;
@@ -519,16 +519,16 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                     const bool inRange = !positiveOnly || t > 0;      // Model.cpp:287 vs :327
                     if (!inRange || !(t == t)) return;
                     if (ANYHIT) {
-                        if (t < FAR_T) stk.bestKey[owner] = 0ull;
+                        if (t < FAR_T) lds.bestKey[owner] = 0ull;
                         return;
                     }
                     const int mm = (int)fbits(B.w);
                     const uint32_t key = S.mdlInfo[4 * mm + 1] + (idw & kTriIdMask);
                     const unsigned long long cand = ((unsigned long long)orderBits(t + 0.0f) << 32) | key;    // -0 orders as +0
                     if (cand < bk) {
-                        atomicMin(&stk.bestKey[owner], cand);
+                        atomicMin(&lds.bestKey[owner], cand);
                         // every lane of this turn has applied its minimum by now: only the lane that holds it sees its own value
-                        if (*(volatile unsigned long long*)&stk.bestKey[owner] == cand) stk.bestRec[owner] = record;
+                        if (*(volatile unsigned long long*)&lds.bestKey[owner] == cand) lds.bestRec[owner] = record;
                     }
                 };
                 testTriangle(A0, B0, C0, first);
@@ -539,22 +539,22 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             {
                 const unsigned long long m = __ballot(goesOn);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (goesOn) stk.triPool[triCount + rank] = (unsigned long long)(first + 2u) | ((unsigned long long)(owner | (chunks << 8)) << 32);
+                if (goesOn) lds.triPool[triCount + rank] = (unsigned long long)(first + 2u) | ((unsigned long long)(owner | (chunks << 8)) << 32);
                 triCount += (uint32_t)__builtin_popcountll(m);
             }
-            timerB.stop(stk, 1);
+            timerB.stop(lds, 1);
         }
         __builtin_amdgcn_wave_barrier();
     }
 
     bool found = false;
     if (hasRay) {
-        const unsigned long long bk = stk.bestKey[lane];
+        const unsigned long long bk = lds.bestKey[lane];
         if (ANYHIT) {
             found = bk == 0ull;
         } else if (bk != init) {
             // the winning triangle once more, for t, u and v
-            const uint32_t record = stk.bestRec[lane];
+            const uint32_t record = lds.bestRec[lane];
             const F4* tp = S.tris + (size_t)record * 3;
             const f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
             V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
@@ -570,11 +570,9 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
         }
     }
     __builtin_amdgcn_wave_barrier();
-    timerWhole.stop(stk, 3);
+    timerWhole.stop(lds, 3);
     return found;
 }
-
-
 
 // ---------------------------------------------------------------- linear object traces
 
@@ -717,7 +715,7 @@ RT_DEV int renormCount(int kind, bool planesRun, bool boxesRun, bool modelsRun) 
 // and a lane without a ray at that point - outside the frame, chain ended, nothing to shade - passes hasRay = false and
 // lends its lane to the others.  `live`: the lane has a camera sample at all.
 template <bool STATS>
-RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V3 d, int px, int py, WaveLds stk, Counters& cnt, Closest& primaryOut) {
+RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V3 d, int px, int py, WaveLds lds, Counters& cnt, Closest& primaryOut) {
     const V3 lightPos = mk(S.lightPos), lightCol = mk(S.lightCol), eye = mk(P.camPos), background = mk(P.background);
     const bool reflections = (P.flags & kCfgReflections) != 0, reflectPlanes = (P.flags & kCfgReflectPlanes) != 0;
     const bool boxesRun = (P.flags & kCfgRenderBoxes) != 0, modelsRun = (P.flags & kCfgRenderModels) != 0;
@@ -742,10 +740,10 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
         if (active) {
             deepest = level;
             cnt.rays++;
-            SectionTimer<STATS> tm; traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h); tm.stop(stk, 4);
+            SectionTimer<STATS> tm; traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h); tm.stop(lds, 4);
         }
         // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
-        if (modelsVisible) tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, nodeCapacity, h, stk, cnt);
+        if (modelsVisible) tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, nodeCapacity, h, lds, cnt);
         if (level == 0 && active) primaryOut = h;
         V3 colour = background;
         bool next = false, lit = false, wantNext = false, add = false, shadowed = false;
@@ -773,7 +771,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
                     else if (h.kind == KIND_BOX && level == 0) { strength = P.boxStrength; add = true; }   // kernels.cu:259
                 }
             }
-            tmShade.stop(stk, 5);
+            tmShade.stop(lds, 5);
         }
         if (level == 0) {
             // shadow rays of the primary hit: the hard shadow ray (kernels.cu:268-277, stops at the first occluder kind), then
@@ -798,13 +796,13 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
                     SectionTimer<STATS> tmSh;
                     bySphere = shadowSpheres(S, biased, sd);
                     byBox = (hard && bySphere) ? false : shadowBoxes(S, biased, sd);
-                    tmSh.stop(stk, 6);
+                    tmSh.stop(lds, 6);
                 }
                 bool byModel = false;
                 if (P.flags & kCfgModelsVisible) {   // the shadow traces ignore renderModels (kernels.cu:304)
                     const bool needModel = lit && !(hard && (bySphere || byBox));
                     Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
-                    byModel = tracePool<true, STATS>(S, needModel, biased, sd, cull, true, P.meshMode, nodeCapacity, dummy, stk, cnt);
+                    byModel = tracePool<true, STATS>(S, needModel, biased, sd, cull, true, P.meshMode, nodeCapacity, dummy, lds, cnt);
                 }
                 if (lit) {
                     if (hard) shadowed = bySphere || byBox || byModel;
@@ -893,8 +891,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     __shared__ unsigned long long poolTris[kTriPool];
     __shared__ unsigned long long profile[16];  // section accumulators of the instrumented kernel: (cycles, executions) x 8
     const uint32_t lane = threadIdx.x;
-    WaveLds stk; stk.prof = profile;
-    stk.rayO = poolRays; stk.rayD = poolRays + kBlockThreads; stk.rayR = poolRays + 2 * kBlockThreads; stk.bestKey = poolBest; stk.bestRec = poolRec; stk.nodePool = poolNodes; stk.triPool = poolTris;
+    WaveLds lds; lds.prof = profile;
+    lds.rayO = poolRays; lds.rayD = poolRays + kBlockThreads; lds.rayR = poolRays + 2 * kBlockThreads; lds.bestKey = poolBest; lds.bestRec = poolRec; lds.nodePool = poolNodes; lds.triPool = poolTris;
     if (STATS) { if (lane < 16) profile[lane] = 0; __syncthreads(); }
 
     // Workgroup B runs on XCD B % 8 (round-robin dispatch).  XCD x takes the tiles at positions x, x + 8, x + 16, ... of the
@@ -959,7 +957,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
             const float offX = antiAlias ? ((sIdx & 2) ? 0.75f : 0.25f) : 0.5f, offY = antiAlias ? ((sIdx & 1) ? 0.75f : 0.25f) : 0.5f;
             V3 p = rasterToCameraSpace(P, (float)x + offX, (float)y + offY);
             Closest ph;
-            V3 c = castSample<STATS>(S, P, inFrame, camPos, normalise(p), x, y, stk, cnt, ph);
+            V3 c = castSample<STATS>(S, P, inFrame, camPos, normalise(p), x, y, lds, cnt, ph);
             if (sIdx == 0) primary = ph;
             total = antiAlias ? total + c : c;
         }
@@ -986,7 +984,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
         unsigned long long* rec = waveClocks + kWaveRecordWords * (size_t)blockIdx.x;
         rec[0] = clockStart;
         rec[1] = __builtin_amdgcn_s_memrealtime();
-        for (int k = 0; k < 16; k++) rec[2 + k] = stk.prof[k];
+        for (int k = 0; k < 16; k++) rec[2 + k] = lds.prof[k];
     }
     if (tileCost && lane == 0) {
         const unsigned long long spent = __builtin_readcyclecounter() - cyclesStart;

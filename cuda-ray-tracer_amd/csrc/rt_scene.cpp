@@ -55,8 +55,17 @@ public:
 
     int build() {
         if (tris_.empty()) return -1;
-        int root = buildRange(0, (int)tris_.size(), 0);
-        if (params_.widen) widen(root);
+        int root;
+        if (params_.sah) {
+            // binary tree by surface-area heuristic; widen() then folds it into nodes of up to eight children
+            root = buildSah(0, (int)tris_.size(), 0);
+            widen(root);
+            deepest = 0;
+            capDepth(root, 0);
+        } else {
+            root = buildRange(0, (int)tris_.size(), 0);
+            if (params_.widen) widen(root);
+        }
         return root;
     }
 
@@ -105,6 +114,81 @@ private:
             nodes[self].child[c] = childIdx;
         }
         return self;
+    }
+
+    // Binned surface-area split of the range, recursively: 16 bins per axis over the bounds of the triangle centres, the
+    // plane with the least area(left) x count(left) + area(right) x count(right) wins.  Ranges whose centres coincide,
+    // and ranges nested deeper than 64 splits, are halved by index.
+    int buildSah(int first, int count, int depth) {
+        const int self = (int)nodes.size();
+        nodes.emplace_back();
+        {
+            TreeNode& n = nodes[self];
+            for (int c = 0; c < 8; c++) n.child[c] = -1;
+            n.first = first; n.count = count;
+            for (int i = 0; i < count; i++) n.box.grow(tris_[perm_[first + i]].box);
+        }
+        if (count <= params_.sahLeafTriangles || count < 2) return self;
+        Box cb;
+        for (int i = 0; i < count; i++) cb.grow(tris_[perm_[first + i]].centre);
+        constexpr int kBins = 16;
+        int bestAxis = -1, bestBin = 0;
+        float bestCost = std::numeric_limits<float>::infinity();
+        for (int a = 0; a < 3 && depth < 64; a++) {
+            const float ext = cb.hi[a] - cb.lo[a];
+            if (!(ext > 0)) continue;
+            Box binBox[kBins];
+            int binCount[kBins] = {};
+            const float scale = (float)kBins / ext;
+            for (int i = 0; i < count; i++) {
+                const BuildTri& t = tris_[perm_[first + i]];
+                int b = (int)((t.centre[a] - cb.lo[a]) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                binCount[b]++;
+                binBox[b].grow(t.box);
+            }
+            float leftArea[kBins];
+            int leftCount[kBins];
+            Box acc;
+            int n = 0;
+            for (int b = 0; b < kBins; b++) {
+                if (binCount[b]) acc.grow(binBox[b]);
+                n += binCount[b];
+                leftArea[b] = n ? area(acc) : 0.0f; leftCount[b] = n;
+            }
+            acc = Box(); n = 0;
+            for (int b = kBins - 1; b >= 1; b--) {
+                if (binCount[b]) acc.grow(binBox[b]);
+                n += binCount[b];
+                if (leftCount[b - 1] == 0 || n == 0) continue;
+                const float cost = leftArea[b - 1] * (float)leftCount[b - 1] + area(acc) * (float)n;
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestBin = b; }     // left = bins below bestBin
+            }
+        }
+        int mid = count / 2;
+        if (bestAxis >= 0) {
+            const float lo = cb.lo[bestAxis], scale = (float)kBins / (cb.hi[bestAxis] - cb.lo[bestAxis]);
+            auto it = std::partition(perm_.begin() + first, perm_.begin() + first + count, [&](int t) {
+                int b = (int)((tris_[(size_t)t].centre[bestAxis] - lo) * scale);
+                b = b < 0 ? 0 : (b >= kBins ? kBins - 1 : b);
+                return b < bestBin;
+            });
+            const int left = (int)(it - (perm_.begin() + first));
+            if (left > 0 && left < count) mid = left;
+        }
+        nodes[self].leaf = false;
+        const int l = buildSah(first, mid, depth + 1);
+        const int r = buildSah(first + mid, count - mid, depth + 1);
+        nodes[self].child[0] = l; nodes[self].child[1] = r;
+        return self;
+    }
+
+    // Nesting deeper than the caller's cap: the subtree becomes one leaf (its triangles are one slice of the permutation).
+    void capDepth(int ni, int depth) {
+        deepest = std::max(deepest, depth);
+        if (nodes[ni].leaf) return;
+        if (depth >= params_.maxDepth) { nodes[ni].leaf = true; for (int c = 0; c < 8; c++) nodes[ni].child[c] = -1; return; }
+        for (int c = 0; c < 8; c++) if (nodes[ni].child[c] >= 0) capDepth(nodes[ni].child[c], depth + 1);
     }
 
     static float area(const Box& b) {
@@ -445,8 +529,9 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err, bool
     }
     OctreeParams params;
     if (s.octreeMaxDepth > 0) params.maxDepth = s.octreeMaxDepth;
-    if (s.octreeLeafTriangles > 0) params.leafTriangles = s.octreeLeafTriangles;
+    if (s.octreeLeafTriangles > 0) { params.leafTriangles = s.octreeLeafTriangles; params.sahLeafTriangles = s.octreeLeafTriangles; }
     if (const char* e = std::getenv("RT_WIDEN")) params.widen = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_SAH")) params.sah = std::atoi(e) != 0;
     if (params.maxDepth > kMaxModelOctreeDepth) { err = "octreeMaxDepth exceeds " + std::to_string(kMaxModelOctreeDepth); return false; }
 
     F4 mat[3];

@@ -156,7 +156,7 @@ typedef struct rt_scene_desc {
     const rt_aabb*   AABBs;    int32_t AABBCount;
     const rt_light*  lights;   int32_t lightCount;
     const rt_model*  models;   int32_t modelCount;
-    /* Octree build parameters (0 = library default: depth 8, 6 triangles per leaf). */
+    /* Tree build parameters (0 = library default: depth 8; 2 triangles per leaf built on the host, 6 on the GPU). */
     int32_t octreeMaxDepth;
     int32_t octreeLeafTriangles;
     /* 0: the octrees are built on the host; 1: on the GPU (Morton sort, one launch per level) - same device layout,
