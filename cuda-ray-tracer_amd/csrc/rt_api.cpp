@@ -84,7 +84,7 @@ struct rt_ctx {
     int framesSinceSelection = 0;     // while nothing is split the selection only runs every kIdleSelectionPeriod-th frame
     int split = 1;                    // 0 disables splitting
     int splitRatio256 = 256;          // a block is split if it costs more than this share (in 1/256) of the evenly spread frame time
-    int splitStartTenths = 16;        // splitting starts when the heaviest block exceeds this many tenths of the evenly packed frame
+    int splitStartTenths = 13;        // splitting starts when the heaviest block exceeds this many tenths of the evenly packed frame
     uint32_t splitFloor = 1500;       // ... and at least this much (wave cycles / 64)
     int residentWaves = 0;
     hipStream_t splitStream = nullptr;  // the split waves run beside the regular ones

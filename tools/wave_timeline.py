@@ -62,4 +62,10 @@ extra = allidx >= (len(clk) - 4096)
 if extra.any():
     print("split waves: %d, duration percentiles (us): %s, sum %.1f ms" % (extra.sum(), {p: round(float(np.percentile(dur[extra], p)), 1) for p in (50, 90, 99, 100)}, dur[extra].sum() / 1e3))
     print("regular waves: duration percentiles (us): %s" % ({p: round(float(np.percentile(dur[~extra], p)), 1) for p in (50, 90, 99, 99.9, 100)},))
+    slow = extra & (dur > np.percentile(dur[extra], 90))
+    for label, sel in (("split waves", extra), ("slowest 10% of the split waves", slow)):
+        turns = sec[sel, 15].sum()
+        print(label + ": %.0f traversal turns/wave with %.1f entries each; node turns %.0f/wave (%.0f cyc), triangle turns %.0f/wave (%.0f cyc), mesh traces %.0f/wave, %.1f%% of the time in mesh traces" % (
+            sec[sel, 15].mean(), raw[sel, 14].astype(np.float64).sum() / max(turns, 1), sec[sel, 1].mean(), sec[sel, 0].sum() / max(sec[sel, 1].sum(), 1),
+            sec[sel, 3].mean(), sec[sel, 2].sum() / max(sec[sel, 3].sum(), 1), sec[sel, 7].mean(), 100 * sec[sel, 6].sum() / tot_cycles[sel].sum()))
 print("slowest waves (wave index, start us, dur us):", [(int(i), round(float((clk[i, 0] - t0) / 100.0), 1), round(float((clk[i, 1] - clk[i, 0]) / 100.0), 1)) for i in idx])
