@@ -85,7 +85,7 @@ struct rt_ctx {
     int split = 1;                    // 0 disables splitting
     int splitRatio256 = 256;          // a block is split if it costs more than this share (in 1/256) of the evenly spread frame time
     int splitStartTenths = 13;        // splitting starts when the heaviest block exceeds this many tenths of the evenly packed frame
-    uint32_t splitFloor = 1500;       // ... and at least this much (wave cycles / 64)
+    uint32_t splitFloor = 4500;       // ... and at least this much (wave run time, 10 ns units)
     int residentWaves = 0;
     hipStream_t splitStream = nullptr;  // the split waves run beside the regular ones
     hipEvent_t evFork = nullptr, evJoin = nullptr;
@@ -188,12 +188,13 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
     }
     uint32_t* cur = ctx->dTileCost + (size_t)ctx->costSlot * kMaxOrderedTiles;
     uint32_t* nxt = ctx->dTileCost + (size_t)(ctx->costSlot ^ 1) * kMaxOrderedTiles;
-    rt::BlockFeedback fb{nullptr, nullptr, nullptr, nullptr, nullptr};
+    rt::BlockFeedback fb{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (feedback) {
         fb.blockCost = ctx->dBlockCost;
         // the selection after the previous frame wrote slot splitSlot ^ 1
         fb.extraCount = &ctx->dSplitState->used[ctx->splitSlot ^ 1];
         fb.hint = ctx->dSplitWaves;
+        fb.frameStart = &ctx->dSplitState->frameStart;
         if (launch.split) { fb.extraMap = ctx->dExtraMap; fb.heavyBits = ctx->dHeavyBits; }
     }
     if (launch.split) {

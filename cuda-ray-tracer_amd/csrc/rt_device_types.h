@@ -129,22 +129,24 @@ enum : int32_t {
 // frame renders the blocks that are worth it with eight waves each (one per pixel row: eight rays, and 56 lanes that only help with the traversal), started
 // before everything else.
 struct BlockFeedback {
-    uint32_t* blockCost;       // per block (tile * 64 + block in tile): cost recorded by the frame being rendered
+    uint32_t* blockCost;       // per block (tile * 64 + block in tile): run time of its wave in the frame being rendered, 10 ns units
     const uint32_t* extraMap;  // block | pixel row << 20 for each split wave
     const uint32_t* extraCount;// number of valid extraMap entries (may exceed kMaxExtraWaves: clamp)
     uint32_t* hint;            // host-visible copy of *extraCount, refreshed by every frame (may be null)
+    unsigned long long* frameStart; // when the frame's first workgroup started, 100 MHz clock (may be null)
     const uint32_t* heavyBits; // one bit per block: set = rendered by split waves, the regular wave skips it
 };
 constexpr int kMaxExtraWaves = 4096;
 constexpr int kMaxSplitBlocks = 1 << 20;    // frames with more blocks per rank are rendered without splitting
 
 // Device-side state of the block selection; two slots used alternately by consecutive frames.
-constexpr int kCostBins = 64;               // two bins per power of two of a block's cost
+constexpr int kCostBins = 128;              // four bins per power of two of a block's cost
 struct SplitState {
     unsigned long long total[2];
     unsigned long long binSum[2][kCostBins];
     uint32_t maxCost[2];
     uint32_t used[2];                       // split waves chosen by the selection of that slot
+    unsigned long long frameStart;          // start of the latest frame, 100 MHz clock
 };
 
 // Per-launch counters (one 64-bit word each), accumulated with one atomic per wave.

@@ -13,7 +13,7 @@ namespace rt {
 // compact tile buffer (P.compactOutput).  ids / tbuf / counters may be null.  stats selects the instrumented kernel.
 hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
                         unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks = nullptr,
-                        const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr, BlockFeedback fb = BlockFeedback{nullptr, nullptr, nullptr, nullptr, nullptr});
+                        const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr, BlockFeedback fb = BlockFeedback{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
 
 // The split waves of the frame's heaviest blocks (fb.extraMap), kMaxExtraWaves workgroups; meant to run concurrently with
 // launchRender of the same frame on another stream.  waveClocks, if given, receives kMaxExtraWaves records.

@@ -880,8 +880,9 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
                                                     unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
                                                     uint32_t* __restrict__ tileCost, BlockFeedback fb) {
     const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
-    const unsigned long long cyclesStart = tileCost ? __builtin_readcyclecounter() : 0ull;
+    const unsigned long long costStart = tileCost ? __builtin_amdgcn_s_memrealtime() : 0ull;    // costs are wall time in 10 ns units
     if (!SPLIT && fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
+    if (!SPLIT && fb.frameStart && blockIdx.x == 0 && threadIdx.x == 0) *fb.frameStart = costStart;
     // 12416 bytes per wave: twelve waves per CU (three per SIMD) fit the 160 KB of LDS.  Measured: at 12928 bytes fewer
     // waves are resident and the frame takes 7 % longer.
     __shared__ f4_t poolRays[3 * kBlockThreads];
@@ -987,11 +988,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
         for (int k = 0; k < 16; k++) rec[2 + k] = lds.prof[k];
     }
     if (tileCost && lane == 0) {
-        const unsigned long long spent = __builtin_readcyclecounter() - cyclesStart;
+        const unsigned long long spent = __builtin_amdgcn_s_memrealtime() - costStart;
         // a split wave stands for the whole block: count it as what one regular wave would have needed.  The factor is a
         // little below the measured speed-up (1.65) so that a block never looks heavier split than it was unsplit, which
         // would keep a frame that does not profit from splitting in the split state.
-        const uint32_t own = (uint32_t)(spent >> 6) + 1u;
+        const uint32_t own = (uint32_t)spent + 1u;
         const uint32_t cost = SPLIT ? own * 3u / 2u : own;
         atomicMax(&tileCost[localTile], cost);   // a tile is as urgent as its slowest wave
         if (fb.blockCost) atomicMax(&fb.blockCost[localTile * (uint32_t)kWavesPerTile + inTile], cost);
@@ -1076,11 +1077,11 @@ hipError_t launchRenderSplit(const DevScene& S, const FrameParams& P, uint8_t* o
     return hipGetLastError();
 }
 
-// Cost bin of a block: two bins per power of two, bin 2e + h holds costs in [(2 + h) << (e - 1), (3 + h) << (e - 1)).
+// Cost bin of a block: four bins per power of two, bin 4e + q holds costs in [(4 + q) << (e - 2), (5 + q) << (e - 2)).
 RT_DEV int costBin(uint32_t c) {
-    if (c < 2u) return (int)c;
+    if (c < 4u) return (int)c;
     const int e = 31 - __builtin_clz(c);
-    return 2 * e + (int)((c >> (e - 1)) & 1u);
+    return 4 * e + (int)((c >> (e - 2)) & 3u);
 }
 
 // After a frame: sum, maximum and a coarse histogram (cost sums per bin) of the block costs, into slot `slot` of the state.
@@ -1123,17 +1124,21 @@ __global__ __launch_bounds__(256) void selectHeavyKernel(uint32_t* __restrict__ 
         const uint32_t maxCost = st->maxCost[slot];
         const bool wasSplit = st->used[slot ^ 1] != 0u;
         const unsigned long long packed = total * 5u / 4u / (slots ? slots : 1u);
-        const bool allow = (unsigned long long)maxCost * 10u > packed * (wasSplit ? startTenths - 3u : startTenths);
+        // the heaviest wave must also span most of the frame as it really ran: with frames of several contexts in flight the
+        // waves of this one share the GPU, every cost is stretched, and the frame is not limited by its heaviest block
+        const unsigned long long span = __builtin_amdgcn_s_memrealtime() - st->frameStart;
+        const bool allow = (unsigned long long)maxCost * 10u > packed * (wasSplit ? startTenths - 3u : startTenths) &&
+                           (unsigned long long)maxCost * 10u >= span * 7u;
         const int top = costBin(maxCost);
         int best = top + 1;                                   // nothing split
         if (ratio256 == 0u) best = 0;
         else if (allow && maxCost > 0u) {
             const unsigned long long unsplitTime = maxCost > packed ? maxCost : packed;
             unsigned long long bestTime = unsplitTime, above = 0;
-            for (int b = top; b >= 2 && b > top - 7; b--) {
+            for (int b = top; b >= 8 && b > top - 14; b--) {
                 above += st->binSum[slot][b];
-                const int e = b >> 1;
-                const unsigned long long edge = (unsigned long long)(2 + (b & 1)) << (e - 1);      // lower edge of bin b
+                const int e = b >> 2;
+                const unsigned long long edge = (unsigned long long)(4 + (b & 3)) << (e - 2);      // lower edge of bin b
                 const unsigned long long extra = above * (8u * kSplitGainDen - kSplitGainNum) / kSplitGainNum;
                 const unsigned long long bulk = (total + ((extra * ratio256) >> 8)) * 5u / 4u / (slots ? slots : 1u);
                 const unsigned long long splitMax = (unsigned long long)maxCost * kSplitGainDen / kSplitGainNum;
