@@ -5,7 +5,7 @@ reflections with maxDepth 2, reflective floor) on N MI355X GPUs of one node.
     python bench.py --gpus 1 --steps 50 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-A step is one frame: every rank renders the 64x64 tiles it owns (tile i -> rank i % N) of the same frame from its own
+A step is one frame: every rank renders the 32x32 tiles it owns (tile i -> rank i % N) of the same frame from its own
 resident copy of the scene, the tile buffers are gathered to rank 0 over RCCL, and rank 0 reassembles the frame.
 The scene, octree and output buffers are resident in HBM before the timed region.  Rank 0 prints one JSON line.
 """

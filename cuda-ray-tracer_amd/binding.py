@@ -13,7 +13,7 @@ from . import ctypes_types as T
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RT_LIB_OVERRIDE") or os.path.join(_HERE, "csrc", "librt_amd.so")
 
-RT_TILE = 64
+RT_TILE = 32
 _lib = None
 
 
@@ -129,7 +129,8 @@ class Renderer:
 
     def profile_waves(self, width, height):
         """Per-wave diagnostic records of one instrumented frame: uint64 array [waves, 18] (see rt_profile_waves)."""
-        cap = ((width + 63) // 64) * ((height + 63) // 64 + 1) * 16 * 4 + 8 * 64 + 4096    # + split waves of the heaviest blocks
+        tiles = ((width + RT_TILE - 1) // RT_TILE) * ((height + RT_TILE - 1) // RT_TILE)
+        cap = (tiles + 8) * (RT_TILE // 8) ** 2 + 4096    # + split waves of the heaviest blocks
         buf = np.zeros((cap, 18), np.uint64)
         n = C.c_size_t(0)
         _check(lib().rt_profile_waves(self._ctx, width, height, buf.ctypes.data, cap, C.byref(n)))

@@ -5,7 +5,7 @@
 
 #include "rt_device_types.h"
 
-#define RT_TILE_PX 64   // must equal RT_TILE of the public header
+#define RT_TILE_PX 32   // must equal RT_TILE of the public header
 
 namespace rt {
 

@@ -32,6 +32,7 @@ constexpr int kBlockThreads = 64;   // render workgroups are single waves
 constexpr uint32_t kSplitGainNum = 5, kSplitGainDen = 3;   // a block rendered by eight split waves is taken to finish 5/3 times sooner (measured: 1.65)
 constexpr int kNodePool = 512;       // mesh traversal: entries of pending children per wave
 constexpr int kTriPool = 560;        // and of pending triangle runs (a node turn can add 8 per lane to fewer than 40)
+constexpr int kExactRankTiles = 4096;  // up to this many tiles are ranked by all-pairs comparison
 constexpr int kWaveRecordWords = 18; // per-wave diagnostic record: start, end, 8 x (cycles, executions)
 #define FAR_T 999.0f
 
@@ -897,7 +898,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     if (STATS) { if (lane < 16) profile[lane] = 0; __syncthreads(); }
 
     // Workgroup B runs on XCD B % 8 (round-robin dispatch).  XCD x takes the tiles at positions x, x + 8, x + 16, ... of the
-    // tile sequence: the 64 waves of a tile share one L2, and every XCD gets the same mix of cheap and expensive tiles.
+    // tile sequence: the 16 waves of a tile share one L2, and every XCD gets the same mix of cheap and expensive tiles.
     uint32_t localTile, inTile, sub = 0;
     bool retire = false;
     if (SPLIT) {
@@ -1010,8 +1011,16 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     }
 }
 
-// order[rank of tile i by descending cost, ties by index] = i.  One wave per tile, lanes share the n comparisons
-// (n is a few hundred tiles at 1080p, 8160 at 8K).  Also clears the other cost buffer for the frame after next.
+// Cost bin of a block: four bins per power of two, bin 4e + q holds costs in [(4 + q) << (e - 2), (5 + q) << (e - 2)).
+RT_DEV int costBin(uint32_t c) {
+    if (c < 4u) return (int)c;
+    const int e = 31 - __builtin_clz(c);
+    return 4 * e + (int)((c >> (e - 2)) & 3u);
+}
+
+// order[rank of tile i by descending cost, ties by index] = i.  One wave per tile, lanes share the n comparisons; used
+// for up to kExactRankTiles tiles (2040 at 1080p: 4 us), larger frames are ranked by cost bin (rankTilesBinnedKernel).  Also clears the
+// other cost buffer for the frame after next.
 __global__ __launch_bounds__(64) void rankTilesKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
                                                       uint32_t* __restrict__ clearNext, int n) {
     const int i = blockIdx.x;
@@ -1075,13 +1084,6 @@ hipError_t launchRenderSplit(const DevScene& S, const FrameParams& P, uint8_t* o
     if (stats) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
     else hipLaunchKernelGGL((renderKernel<false, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
     return hipGetLastError();
-}
-
-// Cost bin of a block: four bins per power of two, bin 4e + q holds costs in [(4 + q) << (e - 2), (5 + q) << (e - 2)).
-RT_DEV int costBin(uint32_t c) {
-    if (c < 4u) return (int)c;
-    const int e = 31 - __builtin_clz(c);
-    return 4 * e + (int)((c >> (e - 2)) & 3u);
 }
 
 // After a frame: sum, maximum and a coarse histogram (cost sums per bin) of the block costs, into slot `slot` of the state.
@@ -1192,9 +1194,47 @@ int residentRenderWaves() {
     return cus * perCu;
 }
 
+// Ranking of many tiles (the all-pairs kernel needs 0.24 ms for the 32 400 tiles of a 7680 x 4320 frame; one global atomic
+// per tile on a few dozen shared counters is no better: same-address atomics from eight XCDs serialise, 0.1 ms for 8160
+// tiles).  One workgroup orders the tiles by cost bin in LDS, sixteen bins per power of two, heaviest bin first, in arrival
+// order within a bin.
+constexpr int kTileBins = 512;
+RT_DEV int tileBin(uint32_t c) {
+    if (c < 16u) return (int)c;
+    const int e = 31 - __builtin_clz(c);
+    return 16 * e + (int)((c >> (e - 4)) & 15u);
+}
+
+__global__ __launch_bounds__(1024) void rankTilesBinnedKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order,
+                                                             uint32_t* __restrict__ clearNext, int n) {
+    __shared__ uint32_t start[kTileBins];
+    const int t = (int)threadIdx.x;
+    if (t < kTileBins) start[t] = 0;
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) atomicAdd(&start[tileBin(cost[i])], 1u);
+    __syncthreads();
+    if (t < 64) {        // first wave: lane l owns bins [8 (63 - l), 8 (63 - l) + 8), so lane order is descending cost
+        const int base = 8 * (63 - t);
+        uint32_t cnt[8], sum = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { cnt[k] = start[base + 7 - k]; sum += cnt[k]; }
+        uint32_t incl = sum;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(incl, off, 64); if (t >= off) incl += v; }
+        uint32_t before = incl - sum;
+#pragma unroll
+        for (int k = 0; k < 8; k++) { start[base + 7 - k] = before; before += cnt[k]; }
+    }
+    __syncthreads();
+    for (int i = t; i < n; i += 1024) {
+        order[atomicAdd(&start[tileBin(cost[i])], 1u)] = (uint32_t)i;
+        clearNext[i] = 0;
+    }
+}
+
 hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, uint32_t* clearNext, int n, hipStream_t stream) {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(rankTilesKernel, dim3((unsigned)n), dim3(64), 0, stream, cost, order, clearNext, n);
+    if (n <= kExactRankTiles) hipLaunchKernelGGL(rankTilesKernel, dim3((unsigned)n), dim3(64), 0, stream, cost, order, clearNext, n);
+    else hipLaunchKernelGGL(rankTilesBinnedKernel, dim3(1), dim3(1024), 0, stream, cost, order, clearNext, n);
     return hipGetLastError();
 }
 

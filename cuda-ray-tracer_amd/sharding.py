@@ -1,6 +1,6 @@
 """Image-tile sharding of one frame over the GPUs of a node.
 
-Tile i (row-major over the grid of 64x64 tiles) belongs to rank i % world.  Each rank renders its tiles into a
+Tile i (row-major over the grid of 32x32 tiles) belongs to rank i % world.  Each rank renders its tiles into a
 compact tile-major buffer (rt_render_tiles_device), the buffers are gathered to rank 0 with torch.distributed
 (backend "nccl" = RCCL over xGMI on the GPUs; "gloo" on CPU tensors in tests), and rank 0 reassembles the frame
 (rt_untile_device).  The numpy functions below state the same layout on the host; tests use them to check the
@@ -8,7 +8,7 @@ device kernels and to rehearse the exchange without a GPU.
 """
 import numpy as np
 
-TILE = 64
+TILE = 32
 
 
 def tile_grid(width, height):

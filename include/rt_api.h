@@ -44,7 +44,7 @@ enum rt_status {
 };
 
 /* Image tiles used to shard a frame over GPUs: RT_TILE x RT_TILE pixels, tile i belongs to rank i % world. */
-#define RT_TILE 64
+#define RT_TILE 32
 
 /*
  * Creates a context on HIP device devices[0] (device_count must be 1: one process drives one GPU; a frame

@@ -295,3 +295,31 @@ def test_gate_boxes_cutting_through_meshes_on_exact_pixel_rays(renderer, oracle,
     assert_parity(stats, st.rays, o_rays)
     assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
     assert (g_ids[..., 0] >> 24 == 4).sum() > 50, "the shrunk gates should still let some mesh pixels through"
+
+
+def test_large_frame_ranked_by_cost_bins(renderer, pkg):
+    """More than 4096 tiles: the dispatch order comes from the bin ranking instead of the all-pairs ranking.  The order
+    (which is not even deterministic within a bin) must not change a byte: compare with a context that dispatches in
+    plain tile order."""
+    import os
+    from cuda_ray_tracer_amd import binding
+    spec, cfg, _, _ = scenes.config_scene(2, detail=0.3)
+    built = scenes.build_scene(spec)
+    w, h = 2304, 2080            # 72 x 65 tiles of 32 x 32
+    assert ((w + binding.RT_TILE - 1) // binding.RT_TILE) * ((h + binding.RT_TILE - 1) // binding.RT_TILE) > 4096
+    os.environ["RT_COST_ORDER"] = "0"
+    try:
+        plain_ctx = binding.Renderer(0)
+    finally:
+        del os.environ["RT_COST_ORDER"]
+    try:
+        plain_ctx.upload(built.desc); plain_ctx.set_state(built.camera, cfg)
+        plain, st0 = plain_ctx.render(w, h)
+    finally:
+        plain_ctx.close()
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    for _ in range(4):           # frame 1 records costs, the later ones are dispatched in ranked order
+        rgb, st = renderer.render(w, h)
+        assert np.array_equal(rgb, plain)
+        assert st.rays == st0.rays
