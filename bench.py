@@ -110,11 +110,16 @@ def main():
     device_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
     torch.cuda.set_device(device_index)
     dev = torch.device("cuda", device_index)
-    if world > 1:
+    # RT_BENCH_TILED=1 runs the N-rank code path (tile buffer, gather, reassembly) with a single rank: measures what the
+    # exchange adds on the host and the GPU when only one GPU is at hand.
+    tiled = world > 1 or os.environ.get("RT_BENCH_TILED", "0") == "1"
+    if tiled:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend=backend)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
 
     load_package()
     from cuda_ray_tracer_amd import binding, scenes
@@ -134,14 +139,14 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     frame = torch.empty(pixels * 3, dtype=torch.uint8, device=dev)
-    in_flight = max(1, args.frames_in_flight) if world == 1 else 1
+    in_flight = max(1, args.frames_in_flight) if not tiled else 1
     lanes = [(r, torch.cuda.current_stream(), frame)]
     for _ in range(in_flight - 1):
         extra = binding.Renderer(device_index)
         extra.upload(built.desc)
         extra.set_state(built.camera, cfg)
         lanes.append((extra, torch.cuda.Stream(device=dev), torch.empty(pixels * 3, dtype=torch.uint8, device=dev)))
-    if world > 1:
+    if tiled:
         # two tile buffers: the gather of frame k (RCCL's own stream) overlaps the render of frame k + 1
         tile_bytes = binding.tile_buffer_bytes(w, h, world)
         tiles = [torch.empty(tile_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
@@ -154,19 +159,29 @@ def main():
 
     kernel_events = []
     pending = []     # (frame slot, async gather handle) of the frame whose tiles are still in flight
+    if tiled:
+        # The exchange (gather, reassembly on rank 0) runs on a stream of its own, so that the render stream goes from
+        # frame to frame without waiting: it only waits before overwriting a tile buffer whose gather has not finished.
+        xs = torch.cuda.Stream(device=dev) if os.environ.get("RT_BENCH_XSTREAM", "1") == "1" else torch.cuda.current_stream()
+        rendered_ev = [torch.cuda.Event() for _ in range(2)]
+        free_ev = [None, None]
 
     def finish_pending():
         while pending:
             slot, work = pending.pop(0)
-            if work is not None:
-                work.wait()                      # the compute stream waits for the gather; the host does not
-            if rank == 0:
-                r.untile_device(w, h, world, gathered[slot].data_ptr(), frame.data_ptr(), stream)
+            with torch.cuda.stream(xs):
+                if work is not None:
+                    work.wait()                  # the exchange stream waits for the gather; the host does not
+                if free_ev[slot] is None:
+                    free_ev[slot] = torch.cuda.Event()
+                free_ev[slot].record(xs)
+                if rank == 0:
+                    r.untile_device(w, h, world, gathered[slot].data_ptr(), frame.data_ptr(), xs.cuda_stream)
 
     step_index = [0]
 
     def step(record):
-        if world == 1:
+        if not tiled:
             ctx, s, buf = lanes[step_index[0] % in_flight]
             step_index[0] += 1
             if record:
@@ -177,20 +192,21 @@ def main():
                 e1.record(s)
                 kernel_events.append((e0, e1))
             return
+        slot = step_index[0] % 2
+        step_index[0] += 1
+        if free_ev[slot] is not None:
+            torch.cuda.current_stream().wait_event(free_ev[slot])
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        if world == 1:
-            r.render_device(w, h, frame.data_ptr(), stream)
-        else:
-            slot = step_index[0] % 2
-            step_index[0] += 1
-            r.render_tiles_device(w, h, rank, world, tiles[slot].data_ptr(), tile_bytes, stream)
+        r.render_tiles_device(w, h, rank, world, tiles[slot].data_ptr(), tile_bytes, stream)
         if record:
             e1.record()
             kernel_events.append((e0, e1))
-        if world > 1:
-            finish_pending()                     # frame k - 1: gathered while frame k was being rendered
+        rendered_ev[slot].record()
+        finish_pending()                         # frame k - 1: gathered while frame k was being rendered
+        with torch.cuda.stream(xs):
+            xs.wait_event(rendered_ev[slot])
             if backend == "nccl":
                 work = dist.gather(tiles[slot], gather_list[slot], dst=0, async_op=True)
             else:
@@ -199,10 +215,10 @@ def main():
                 if rank == 0:
                     gathered[slot].copy_(host_gathered)
                 work = None
-            pending.append((slot, work))
+        pending.append((slot, work))
 
     def fence():
-        if world > 1:
+        if tiled:
             finish_pending()
             torch.cuda.synchronize()
             dist.barrier()
@@ -214,6 +230,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
+    enqueue = time.perf_counter() - t0       # host time to issue the steps (the GPU may still be busy)
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -252,8 +269,8 @@ def main():
                        "triangles": int(info.triangleCount), "octree_nodes": int(info.nodeCount), "rays_per_frame": rays,
                        "rays_per_pixel": rays / pixels, "tile": binding.RT_TILE,
                        "frames_in_flight": in_flight,
-                       "parallelism": "1 GPU" if world == 1 else f"image tiles over {world} GPUs, scene replicated, RCCL gather to rank 0"},
-            "kernel_ms": kernel_ms,
+                       "parallelism": ("1 GPU" if not tiled else "1 GPU through the tile / gather / reassembly path (rehearsal)") if world == 1 else f"image tiles over {world} GPUs, scene replicated, RCCL gather to rank 0"},
+            "kernel_ms": kernel_ms, "host_issue_ms_per_step": enqueue * 1e3 / args.steps,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_ray": b_ray, "node_tests_per_ray": st.node_tests / rays, "tri_tests_per_ray": st.tri_tests / rays,
@@ -268,7 +285,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     r.close()
-    if world > 1:
+    if tiled:
         dist.destroy_process_group()
 
 

@@ -97,6 +97,7 @@ struct FrameParams {
     int32_t compactOutput;     // 1: write tile-major into the rank's compact buffer, 0: row-major full frame
     int32_t blockOrder;        // workgroup -> tile mapping: 0 tile by tile, 2 tiles interleaved over the XCDs
     int32_t nodePoolEntries;   // capacity of the traversal's pool of pending children that a wave may use (96 .. the compiled size; smaller values only serve tests)
+    int32_t traversal;         // kTrav* bits; bits 8-15: sibling expansion applies while the pool holds at most 8 x this many entries
     int32_t split;             // 1: the grid starts with kMaxExtraWaves workgroups for split blocks (BlockFeedback::extraMap)
     float camPos[3], camUp[3], camRight[3], camDir[3], fovFactor;
     // SceneConfig
@@ -116,6 +117,8 @@ enum : uint32_t {
     kCfgModelsVisible = 1u << 12   // false when the selected mesh mode renders nothing
 };
 
+enum : uint32_t { kTravDirectStart = 1u << 0, kTravExpandSiblings = 1u << 1 };
+
 // Mesh hit modes of Model::hit (Model.cpp:161-357) that render something.
 enum : int32_t {
     kMeshWholeBox = 0,   // whole-model box gate + every triangle, t > 0 (Model.cpp:275-317)
@@ -129,7 +132,7 @@ enum : int32_t {
 // frame renders the blocks that are worth it with eight waves each (one per pixel row: eight rays, and 56 lanes that only help with the traversal), started
 // before everything else.
 struct BlockFeedback {
-    uint32_t* blockCost;       // per block (tile * 64 + block in tile): run time of its wave in the frame being rendered, 10 ns units
+    uint32_t* blockCost;       // per block (tile * blocks per tile + block in tile): run time of its wave in the frame being rendered, 10 ns units
     const uint32_t* extraMap;  // block | pixel row << 20 for each split wave
     const uint32_t* extraCount;// number of valid extraMap entries (may exceed kMaxExtraWaves: clamp)
     uint32_t* hint;            // host-visible copy of *extraCount, refreshed by every frame (may be null)

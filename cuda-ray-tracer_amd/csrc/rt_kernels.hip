@@ -32,6 +32,7 @@ constexpr int kBlockThreads = 64;   // render workgroups are single waves
 constexpr uint32_t kSplitGainNum = 5, kSplitGainDen = 3;   // a block rendered by eight split waves is taken to finish 5/3 times sooner (measured: 1.65)
 constexpr int kNodePool = 512;       // mesh traversal: entries of pending children per wave
 constexpr int kTriPool = 560;        // and of pending triangle runs (a node turn can add 8 per lane to fewer than 40)
+constexpr int kDirectStartModels = 6;  // up to this many models a trace can start at the model roots (one pool entry per ray and model)
 constexpr int kExactRankTiles = 4096;  // up to this many tiles are ranked by all-pairs comparison
 constexpr int kWaveRecordWords = 18; // per-wave diagnostic record: start, end, 8 x (cycles, executions)
 #define FAR_T 999.0f
@@ -337,7 +338,7 @@ RT_DEV float orderFloat(uint32_t m) { return ubits((m & 0x80000000u) ? (m & 0x7f
 // level) until there is room again.  A node turn adds at most eight triangle runs per
 // lane, and is only taken with fewer than 40 runs pending.
 template <bool ANYHIT, bool STATS>
-RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t nodeCapacity, Closest& best, WaveLds lds, Counters& cnt) {
+RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t nodeCapacity, uint32_t trav, Closest& best, WaveLds lds, Counters& cnt) {
     if (S.forestRoot == kNoRoot) return false;
     SectionTimer<STATS> timerWhole;
     const uint32_t lane = threadIdx.x & 63u;
@@ -384,7 +385,18 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
     }
     // one pseudo entry per ray that resolves to the forest root
     uint32_t nodeCount, triCount = 0;
-    {
+    if ((trav & kTravDirectStart) && pregated && nMdl <= kDirectStartModels && (uint32_t)nMdl * 64u + 88u <= nodeCapacity) {
+        // few models, gates known: one entry per ray and model whose gate the ray passed, resolving to that model's root
+        nodeCount = 0;
+        for (int j = 0; j < nMdl; j++) {
+            const uint32_t root = S.mdlInfo[4 * j];
+            const bool in = enters && ((gateBits >> j) & 1ull) != 0 && root != kNoRoot;
+            const unsigned long long m = __ballot(in);
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            if (in) lds.nodePool[nodeCount + rank] = (unsigned long long)root | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
+            nodeCount += (uint32_t)__builtin_popcountll(m);
+        }
+    } else {
         const unsigned long long m = __ballot(enters);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
         if (enters) lds.nodePool[rank] = (unsigned long long)S.forestRoot | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
@@ -459,7 +471,30 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 // the leaf references are fetched only by the lanes that hit a leaf (the line is in the L1 by now)
                 if (pend != 0u) { ra = *reinterpret_cast<const u4_t*>(np + 5); rb = *reinterpret_cast<const u4_t*>(np + 6); }
             }
-            {
+            // While the pool holds fewer entries than the wave has lanes, every hit child gets an entry of its own (farthest
+            // first, so that the nearest ends up on top) and the next turn visits siblings side by side instead of one per turn.
+            bool expand = false;
+            if (trav & kTravExpandSiblings) {
+                uint32_t total = nodeCount;
+#pragma unroll
+                for (int k = 0; k < 8; k++) total += (uint32_t)__builtin_popcountll(__ballot(((childHits >> k) & 1u) != 0u));
+                expand = total <= ((trav >> 8) & 0xffu) * 8u;
+            }
+            if (expand) {
+                uint32_t waiting = childHits;
+                for (;;) {
+                    const bool more = waiting != 0u;
+                    const unsigned long long m = __ballot(more);
+                    if (m == 0ull) break;
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    if (more) {
+                        const uint32_t k = 31u - (uint32_t)__builtin_clz(waiting);
+                        waiting &= ~(1u << k);
+                        lds.nodePool[nodeCount + rank] = (unsigned long long)childBase | ((unsigned long long)(childImask | (1u << (k + 8u)) | (owner << 16) | (chunkMask << 24)) << 32);
+                    }
+                    nodeCount += (uint32_t)__builtin_popcountll(m);
+                }
+            } else {
                 const bool down = childHits != 0u;
                 const unsigned long long m = __ballot(down);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -744,7 +779,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
             SectionTimer<STATS> tm; traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h); tm.stop(lds, 4);
         }
         // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
-        if (modelsVisible) tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, nodeCapacity, h, lds, cnt);
+        if (modelsVisible) tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, nodeCapacity, (uint32_t)P.traversal, h, lds, cnt);
         if (level == 0 && active) primaryOut = h;
         V3 colour = background;
         bool next = false, lit = false, wantNext = false, add = false, shadowed = false;
@@ -803,7 +838,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
                 if (P.flags & kCfgModelsVisible) {   // the shadow traces ignore renderModels (kernels.cu:304)
                     const bool needModel = lit && !(hard && (bySphere || byBox));
                     Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
-                    byModel = tracePool<true, STATS>(S, needModel, biased, sd, cull, true, P.meshMode, nodeCapacity, dummy, lds, cnt);
+                    byModel = tracePool<true, STATS>(S, needModel, biased, sd, cull, true, P.meshMode, nodeCapacity, (uint32_t)P.traversal, dummy, lds, cnt);
                 }
                 if (lit) {
                     if (hard) shadowed = bySphere || byBox || byModel;
@@ -1059,6 +1094,21 @@ __global__ __launch_bounds__(256) void untileKernel(const uint8_t* __restrict__ 
     }
 }
 
+// The same for frames whose width is a multiple of 16 pixels: a tile row is 96 contiguous bytes in both layouts and every
+// 16-byte piece of the frame lies inside one tile row, so a thread moves one aligned 16-byte piece.
+__global__ __launch_bounds__(256) void untileWideKernel(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ out, int width, int height,
+                                                        int world, int tilesX, size_t perRankBytes) {
+    const size_t rowBytes = (size_t)width * 3;
+    const size_t o = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (o >= rowBytes * (size_t)height) return;
+    const uint32_t y = (uint32_t)(o / rowBytes), xb = (uint32_t)(o % rowBytes);
+    constexpr uint32_t kTileRowBytes = RT_TILE_PX * 3;
+    const uint32_t tile = (y / RT_TILE_PX) * (uint32_t)tilesX + xb / kTileRowBytes;
+    const uint32_t rank = tile % (uint32_t)world, local = tile / (uint32_t)world;
+    const size_t src = (size_t)rank * perRankBytes + (size_t)local * (RT_TILE_PX * kTileRowBytes) + (size_t)(y % RT_TILE_PX) * kTileRowBytes + xb % kTileRowBytes;
+    *reinterpret_cast<u4_t*>(out + o) = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(gathered + src));
+}
+
 // ---------------------------------------------------------------- launch wrappers (host)
 
 unsigned launchGridBlocks(const FrameParams& P) {
@@ -1241,6 +1291,12 @@ hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, uint32_t* clea
 hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX, size_t perRankBytes,
                         hipStream_t stream) {
     size_t total = (size_t)width * (size_t)height * 3;
+    static_assert((RT_TILE_PX * 3) % 16 == 0, "a tile row must be a whole number of 16-byte pieces");
+    if (width % 16 == 0 && perRankBytes % 16 == 0 && (reinterpret_cast<uintptr_t>(gathered) | reinterpret_cast<uintptr_t>(out)) % 16 == 0) {
+        const size_t pieces = total / 16;
+        hipLaunchKernelGGL(untileWideKernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, gathered, out, width, height, world, tilesX, perRankBytes);
+        return hipGetLastError();
+    }
     size_t threads = (total + 3) / 4;
     dim3 grid((unsigned)((threads + 255) / 256)), block(256);
     hipLaunchKernelGGL(untileKernel, grid, block, 0, stream, gathered, out, width, height, world, tilesX, perRankBytes);

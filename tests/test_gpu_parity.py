@@ -117,7 +117,7 @@ def _render_tiles_emulated(renderer, w, h, world):
 
 
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
-@pytest.mark.parametrize("size", [(640, 360), (333, 201)])
+@pytest.mark.parametrize("size", [(640, 360), (333, 201), (656, 200)])
 def test_tile_sharded_frame_equals_single_gpu_frame(renderer, world, size):
     """The multi-GPU invariant: tiles rendered per rank and reassembled == the one-launch frame, byte for byte."""
     import torch  # noqa: F401  (first, so that the library shares torch's HIP runtime)
