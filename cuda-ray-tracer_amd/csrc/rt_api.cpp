@@ -456,6 +456,11 @@ int rt_update_frame_state(rt_ctx* ctx, const rt_camera* cam, const rt_config* cf
     float* dst[4] = {p.camPos, p.camUp, p.camRight, p.camDir};
     for (int i = 0; i < 4; i++) std::memcpy(dst[i], src[i], 3 * sizeof(float));
     p.fovFactor = cam->fovFactor;
+    {   // kernels.cu:48,56: v = normalise(cameraPosition) = position / sqrt((x x + y y) + z z), IEEE float without contraction
+        const float x = p.camPos[0], y = p.camPos[1], z = p.camPos[2];
+        const float len = std::sqrt(x * x + y * y + z * z);
+        p.eyeDir[0] = x / len; p.eyeDir[1] = y / len; p.eyeDir[2] = z / len;
+    }
     p.shadowBias = cfg->shadowBias; p.shadowIntensity = cfg->shadowIntensity;
     p.sphereStrength = cfg->sphereReflectionStrength; p.planeStrength = cfg->planeReflectionStrength;
     p.boxStrength = cfg->AABBReflectionStrength; p.modelStrength = cfg->modelReflectionStrength;

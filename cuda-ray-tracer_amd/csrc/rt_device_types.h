@@ -100,6 +100,7 @@ struct FrameParams {
     int32_t traversal;         // kTrav* bits; bits 8-15: sibling expansion applies while the pool holds at most 8 x this many entries
     int32_t split;             // 1: the grid starts with kMaxExtraWaves workgroups for split blocks (BlockFeedback::extraMap)
     float camPos[3], camUp[3], camRight[3], camDir[3], fovFactor;
+    float eyeDir[3];           // camPos / length(camPos) in float, component by component (the view vector of the specular term)
     // SceneConfig
     float shadowBias, shadowIntensity;
     float sphereStrength, planeStrength, boxStrength, modelStrength;

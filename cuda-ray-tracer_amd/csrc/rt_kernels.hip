@@ -669,7 +669,9 @@ RT_DEV bool shadowBoxes(const DevScene& S, V3 o, V3 d) {
 
 // ---------------------------------------------------------------- shading
 
-RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 eye, V3 normal, const FrameParams& P, int px, int py) {
+// v = normalise(cameraPosition) (kernels.cu:20-65 evaluates it per pixel; it is the same for the whole frame and arrives in
+// the frame parameters, computed on the host with the same three divisions and square root).
+RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 v, V3 normal, const FrameParams& P, int px, int py) {
     V3 colour = mk(0, 0, 0);
     V3 L = normalise(lightPos - point);
     if (P.flags & kCfgAmbient) colour = (lightCol * mat.ka) * mat.ambient;
@@ -682,13 +684,11 @@ RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 eye, V
             for (int i = 0; i < P.softNum; i++) {
                 V3 ps = lightSampleOffset(sampleSeed(px, py, i), P.softRadius);
                 V3 Ls = normalise((lightPos + ps) - point);
-                V3 v = normalise(eye);
                 V3 r = normalise(neg(reflect(Ls, normal)));
                 float RdotV = selMax(dot(r, v), 0.0f);
                 colour = colour + (lightCol * mat.specular) * powf(RdotV, mat.shininess);
             }
         } else {
-            V3 v = normalise(eye);
             V3 r = normalise(neg(reflect(L, normal)));
             float RdotV = selMax(dot(r, v), 0.0f);
             colour = colour + (lightCol * mat.specular) * powf(RdotV, mat.shininess);
@@ -752,7 +752,7 @@ RT_DEV int renormCount(int kind, bool planesRun, bool boxesRun, bool modelsRun) 
 // lends its lane to the others.  `live`: the lane has a camera sample at all.
 template <bool STATS>
 RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V3 d, int px, int py, WaveLds lds, Counters& cnt, Closest& primaryOut) {
-    const V3 lightPos = mk(S.lightPos), lightCol = mk(S.lightCol), eye = mk(P.camPos), background = mk(P.background);
+    const V3 lightPos = mk(S.lightPos), lightCol = mk(S.lightCol), eye = mk(P.eyeDir), background = mk(P.background);
     const bool reflections = (P.flags & kCfgReflections) != 0, reflectPlanes = (P.flags & kCfgReflectPlanes) != 0;
     const bool boxesRun = (P.flags & kCfgRenderBoxes) != 0, modelsRun = (P.flags & kCfgRenderModels) != 0;
     const bool modelsVisible = modelsRun && (P.flags & kCfgModelsVisible) != 0;
