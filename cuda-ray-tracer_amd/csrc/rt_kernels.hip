@@ -886,6 +886,24 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
 }
 
 
+// Copies every field of a kernel-argument struct into a scalar register of its own (an explicit move, which the register
+// coalescer cannot fold back into the loaded tuple): the first `pointers` fields as 64-bit values, the rest as 32-bit values.
+template <int pointers, typename T>
+RT_DEV void separateScalars(T& v) {
+    static_assert(sizeof(T) % 4 == 0 && sizeof(T) >= 8 * (size_t)pointers, "struct of pointers followed by 32-bit fields");
+    constexpr int words = (int)((sizeof(T) - 8 * (size_t)pointers) / 4);
+    unsigned long long p[pointers > 0 ? pointers : 1];
+    uint32_t w[words > 0 ? words : 1];
+    __builtin_memcpy(p, &v, 8 * (size_t)pointers);
+    __builtin_memcpy(w, reinterpret_cast<const char*>(&v) + 8 * (size_t)pointers, 4 * (size_t)words);
+#pragma unroll
+    for (int i = 0; i < pointers; i++) { unsigned long long q; asm volatile("s_mov_b64 %0, %1" : "=s"(q) : "s"(p[i])); p[i] = q; }
+#pragma unroll
+    for (int i = 0; i < words; i++) { uint32_t q; asm volatile("s_mov_b32 %0, %1" : "=s"(q) : "s"(w[i])); w[i] = q; }
+    __builtin_memcpy(&v, p, 8 * (size_t)pointers);
+    __builtin_memcpy(reinterpret_cast<char*>(&v) + 8 * (size_t)pointers, w, 4 * (size_t)words);
+}
+
 RT_DEV V3 rasterToCameraSpace(const FrameParams& P, float x, float y) {
     float ndcx = x / (float)P.width, ndcy = y / (float)P.height;
     float sx = 2 * ndcx - 1, sy = 1 - 2 * ndcy;
@@ -911,10 +929,14 @@ RT_DEV uint32_t evenBits3(uint32_t v) { return (v & 1u) | ((v >> 1) & 2u) | ((v 
 // rendering one pixel row of one of the frame's heaviest blocks: eight lanes bring a pixel, the other 56 only help with
 // the mesh traversal.
 template <bool STATS, bool SPLIT>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3))) void renderKernel(DevScene S, FrameParams P, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3))) void renderKernel(DevScene sceneArg, FrameParams frameArg, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
                                                     float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
                                                     unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
                                                     uint32_t* __restrict__ tileCost, BlockFeedback fb) {
+    // The argument structs arrive through 16-dword scalar loads, and a value that lives in such a register tuple is spilled
+    // and brought back sixteen lanes at a time: every field becomes a scalar value of its own here.
+    DevScene S = sceneArg; FrameParams P = frameArg;
+    separateScalars<19>(S); separateScalars<0>(P);
     const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
     const unsigned long long costStart = tileCost ? __builtin_amdgcn_s_memrealtime() : 0ull;    // costs are wall time in 10 ns units
     if (!SPLIT && fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
