@@ -87,9 +87,11 @@ def main():
     ap.add_argument("--height", type=int, default=0)
     ap.add_argument("--leaf", type=int, default=0, help="octree leaf size override (0 = library default)")
     ap.add_argument("--depth", type=int, default=0, help="octree depth cap override (0 = library default)")
-    ap.add_argument("--frames-in-flight", type=int, default=1,
-                    help="1 GPU: consecutive frames alternate over this many HIP streams (one renderer context and frame buffer "
-                         "each), so the start of a frame overlaps the slow tail of the frame before it")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="consecutive frames alternate over this many HIP streams (one renderer context each), so the start of a "
+                         "frame overlaps the slow tail of the frame before it; 0 = 1 on one GPU (the roofline line is defined on "
+                         "launches that do not overlap), 2 on several GPUs (a rank's share of a frame is as long as its heaviest "
+                         "8x8 block and leaves most of the GPU idle)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out", type=str, default="", help="write the last frame as PNG (rank 0)")
     args = ap.parse_args()
@@ -139,19 +141,20 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     frame = torch.empty(pixels * 3, dtype=torch.uint8, device=dev)
-    in_flight = max(1, args.frames_in_flight) if not tiled else 1
+    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world > 1 else 1)
     lanes = [(r, torch.cuda.current_stream(), frame)]
     for _ in range(in_flight - 1):
         extra = binding.Renderer(device_index)
         extra.upload(built.desc)
         extra.set_state(built.camera, cfg)
-        lanes.append((extra, torch.cuda.Stream(device=dev), torch.empty(pixels * 3, dtype=torch.uint8, device=dev)))
+        lanes.append((extra, torch.cuda.Stream(device=dev), None if tiled else torch.empty(pixels * 3, dtype=torch.uint8, device=dev)))
     if tiled:
-        # two tile buffers: the gather of frame k (RCCL's own stream) overlaps the render of frame k + 1
+        # at least two tile buffers: the gather of frame k (RCCL's own stream) overlaps the render of frame k + 1
+        slots = max(2, in_flight)
         tile_bytes = binding.tile_buffer_bytes(w, h, world)
-        tiles = [torch.empty(tile_bytes, dtype=torch.uint8, device=dev) for _ in range(2)]
-        gathered = [torch.empty(tile_bytes * world, dtype=torch.uint8, device=dev) for _ in range(2)] if rank == 0 else [None, None]
-        gather_list = [list(g.chunk(world)) for g in gathered] if rank == 0 else [None, None]
+        tiles = [torch.empty(tile_bytes, dtype=torch.uint8, device=dev) for _ in range(slots)]
+        gathered = [torch.empty(tile_bytes * world, dtype=torch.uint8, device=dev) for _ in range(slots)] if rank == 0 else [None] * slots
+        gather_list = [list(g.chunk(world)) for g in gathered] if rank == 0 else [None] * slots
         if backend != "nccl":
             host_tiles = torch.empty(tile_bytes, dtype=torch.uint8)
             host_gathered = torch.empty(tile_bytes * world, dtype=torch.uint8) if rank == 0 else None
@@ -163,8 +166,8 @@ def main():
         # The exchange (gather, reassembly on rank 0) runs on a stream of its own, so that the render stream goes from
         # frame to frame without waiting: it only waits before overwriting a tile buffer whose gather has not finished.
         xs = torch.cuda.Stream(device=dev) if os.environ.get("RT_BENCH_XSTREAM", "1") == "1" else torch.cuda.current_stream()
-        rendered_ev = [torch.cuda.Event() for _ in range(2)]
-        free_ev = [None, None]
+        rendered_ev = [torch.cuda.Event() for _ in range(slots)]
+        free_ev = [None] * slots
 
     def finish_pending():
         while pending:
@@ -192,18 +195,19 @@ def main():
                 e1.record(s)
                 kernel_events.append((e0, e1))
             return
-        slot = step_index[0] % 2
+        slot = step_index[0] % slots
+        ctx, s, _ = lanes[step_index[0] % in_flight]
         step_index[0] += 1
         if free_ev[slot] is not None:
-            torch.cuda.current_stream().wait_event(free_ev[slot])
+            s.wait_event(free_ev[slot])
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-        r.render_tiles_device(w, h, rank, world, tiles[slot].data_ptr(), tile_bytes, stream)
+            e0.record(s)
+        ctx.render_tiles_device(w, h, rank, world, tiles[slot].data_ptr(), tile_bytes, s.cuda_stream)
         if record:
-            e1.record()
+            e1.record(s)
             kernel_events.append((e0, e1))
-        rendered_ev[slot].record()
+        rendered_ev[slot].record(s)
         finish_pending()                         # frame k - 1: gathered while frame k was being rendered
         with torch.cuda.stream(xs):
             xs.wait_event(rendered_ev[slot])
@@ -284,7 +288,8 @@ def main():
             Image.fromarray(frame.cpu().numpy().reshape(h, w, 3)).save(args.out)
         print(json.dumps(out), flush=True)
 
-    r.close()
+    for ctx, _, _ in lanes:
+        ctx.close()
     if tiled:
         dist.destroy_process_group()
 
