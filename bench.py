@@ -92,10 +92,14 @@ def main():
                          "frame overlaps the slow tail of the frame before it; 0 = 1 on one GPU (the roofline line is defined on "
                          "launches that do not overlap), 2 on several GPUs (a rank's share of a frame is as long as its heaviest "
                          "8x8 block and leaves most of the GPU idle)")
+    ap.add_argument("--tile-slots", type=int, default=4, help="several GPUs: tile buffers per rank (frames that can be between render and gather)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out", type=str, default="", help="write the last frame as PNG (rank 0)")
     args = ap.parse_args()
 
+    if os.environ.get("RT_BENCH_WATCHDOG"):      # diagnostic: dump the Python stacks if the run is still going after n seconds
+        import faulthandler
+        faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
     import torch
     import torch.distributed as dist
 
@@ -141,7 +145,15 @@ def main():
 
     stream = torch.cuda.current_stream().cuda_stream
     frame = torch.empty(pixels * 3, dtype=torch.uint8, device=dev)
-    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else (2 if world > 1 else 1)
+    # RT_BENCH_EMULATE_WORLD=n with one tiled rank: that rank renders, gathers and reassembles the share it would have among
+    # n ranks (the other shares stay black) - what one rank of an n-GPU run costs on the host and on the GPU.
+    share = world
+    if tiled and world == 1 and int(os.environ.get("RT_BENCH_EMULATE_WORLD", "0")) > 1:
+        share = int(os.environ["RT_BENCH_EMULATE_WORLD"])
+    in_flight = args.frames_in_flight if args.frames_in_flight > 0 else (2 if share > 1 else 1)
+    if os.environ.get("RT_BENCH_OWN_STREAM", "0") == "1":     # lane 0 on a stream of its own instead of the default stream
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev))
+        stream = torch.cuda.current_stream().cuda_stream
     lanes = [(r, torch.cuda.current_stream(), frame)]
     for _ in range(in_flight - 1):
         extra = binding.Renderer(device_index)
@@ -149,18 +161,20 @@ def main():
         extra.set_state(built.camera, cfg)
         lanes.append((extra, torch.cuda.Stream(device=dev), None if tiled else torch.empty(pixels * 3, dtype=torch.uint8, device=dev)))
     if tiled:
-        # at least two tile buffers: the gather of frame k (RCCL's own stream) overlaps the render of frame k + 1
-        slots = max(2, in_flight)
-        tile_bytes = binding.tile_buffer_bytes(w, h, world)
+        # several tile buffers: the gather of frame k (RCCL's own stream) overlaps the render of the frames after it; a buffer is
+        # rendered into again only when its gather has finished, so their number bounds how many frames the pipeline holds
+        slots = max(2, in_flight, args.tile_slots)
+        tile_bytes = binding.tile_buffer_bytes(w, h, share)
         tiles = [torch.empty(tile_bytes, dtype=torch.uint8, device=dev) for _ in range(slots)]
-        gathered = [torch.empty(tile_bytes * world, dtype=torch.uint8, device=dev) for _ in range(slots)] if rank == 0 else [None] * slots
-        gather_list = [list(g.chunk(world)) for g in gathered] if rank == 0 else [None] * slots
+        gathered = [torch.zeros(tile_bytes * share, dtype=torch.uint8, device=dev) for _ in range(slots)] if rank == 0 else [None] * slots
+        gather_list = [list(g.chunk(share))[:world] for g in gathered] if rank == 0 else [None] * slots
         if backend != "nccl":
             host_tiles = torch.empty(tile_bytes, dtype=torch.uint8)
             host_gathered = torch.empty(tile_bytes * world, dtype=torch.uint8) if rank == 0 else None
             host_list = list(host_gathered.chunk(world)) if rank == 0 else None
 
     kernel_events = []
+    host_parts = [0.0, 0.0, 0.0]    # host seconds spent issuing: render, completion of the previous frame, gather
     pending = []     # (frame slot, async gather handle) of the frame whose tiles are still in flight
     if tiled:
         # The exchange (gather, reassembly on rank 0) runs on a stream of its own, so that the render stream goes from
@@ -179,7 +193,7 @@ def main():
                     free_ev[slot] = torch.cuda.Event()
                 free_ev[slot].record(xs)
                 if rank == 0:
-                    r.untile_device(w, h, world, gathered[slot].data_ptr(), frame.data_ptr(), xs.cuda_stream)
+                    r.untile_device(w, h, share, gathered[slot].data_ptr(), frame.data_ptr(), xs.cuda_stream)
 
     step_index = [0]
 
@@ -198,17 +212,27 @@ def main():
         slot = step_index[0] % slots
         ctx, s, _ = lanes[step_index[0] % in_flight]
         step_index[0] += 1
+        h0 = time.perf_counter()
         if free_ev[slot] is not None:
             s.wait_event(free_ev[slot])
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
-        ctx.render_tiles_device(w, h, rank, world, tiles[slot].data_ptr(), tile_bytes, s.cuda_stream)
+        ctx.render_tiles_device(w, h, rank, share, tiles[slot].data_ptr(), tile_bytes, s.cuda_stream)
         if record:
             e1.record(s)
             kernel_events.append((e0, e1))
         rendered_ev[slot].record(s)
+        h1 = time.perf_counter()
         finish_pending()                         # frame k - 1: gathered while frame k was being rendered
+        h2 = time.perf_counter()
+        host_parts[0] += h1 - h0; host_parts[1] += h2 - h1; host_parts[2] -= h2
+        try:
+            issue_gather(slot)
+        finally:
+            host_parts[2] += time.perf_counter()
+
+    def issue_gather(slot):
         with torch.cuda.stream(xs):
             xs.wait_event(rendered_ev[slot])
             if backend == "nccl":
@@ -224,6 +248,14 @@ def main():
     def fence():
         if tiled:
             finish_pending()
+            if os.environ.get("RT_BENCH_DEBUG_HANG"):
+                t_end = time.perf_counter() + 5.0
+                while time.perf_counter() < t_end and not all(l[1].query() for l in lanes) or not xs.query():
+                    if time.perf_counter() >= t_end:
+                        break
+                    time.sleep(0.01)
+                print("lanes done:", [l[1].query() for l in lanes], "xs done:", xs.query(), "rendered:", [e.query() for e in rendered_ev],
+                      "free:", [e.query() if e is not None else None for e in free_ev], "steps issued:", step_index[0], file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
@@ -273,8 +305,9 @@ def main():
                        "triangles": int(info.triangleCount), "octree_nodes": int(info.nodeCount), "rays_per_frame": rays,
                        "rays_per_pixel": rays / pixels, "tile": binding.RT_TILE,
                        "frames_in_flight": in_flight,
-                       "parallelism": ("1 GPU" if not tiled else "1 GPU through the tile / gather / reassembly path (rehearsal)") if world == 1 else f"image tiles over {world} GPUs, scene replicated, RCCL gather to rank 0"},
+                       "parallelism": ("1 GPU" if not tiled else f"1 GPU through the tile / gather / reassembly path (rehearsal, share of {share} ranks)") if world == 1 else f"image tiles over {world} GPUs, scene replicated, RCCL gather to rank 0"},
             "kernel_ms": kernel_ms, "host_issue_ms_per_step": enqueue * 1e3 / args.steps,
+            "host_issue_parts_ms": {k: v * 1e3 / (args.steps + args.warmup) for k, v in zip(("render", "complete_previous", "gather"), host_parts)} if tiled else None,
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
                          "bytes_per_ray": b_ray, "node_tests_per_ray": st.node_tests / rays, "tri_tests_per_ray": st.tri_tests / rays,

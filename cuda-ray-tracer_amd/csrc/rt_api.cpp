@@ -302,10 +302,11 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     c->residentWaves = rt::residentRenderWaves();
     if (c->residentWaves <= 0) c->split = 0;
     if (c->split) {
-        // highest priority: the split waves must get wave slots ahead of the regular waves of the same frame
-        int leastPriority = 0, greatestPriority = 0;
-        hipError_t se = hipDeviceGetStreamPriorityRange(&leastPriority, &greatestPriority);
-        if (se == hipSuccess) se = hipStreamCreateWithPriority(&c->splitStream, hipStreamNonBlocking, greatestPriority);
+        // Default priority.  The split launch is issued before the regular one, which is enough for its waves to get their
+        // slots first.  With a high-priority stream the frame time was the same, and a process with two contexts plus an
+        // exchange stream (six streams on four hardware queues) stopped making progress on the GPU: a waiting high-priority
+        // queue kept the queue it waited for from being scheduled.
+        hipError_t se = hipStreamCreateWithFlags(&c->splitStream, hipStreamNonBlocking);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming);
         if (se == hipSuccess) se = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming);
         void* hp = nullptr;
