@@ -88,8 +88,6 @@ struct rt_ctx {
     int splitStartTenths = 13;        // splitting starts when the heaviest block exceeds this many tenths of the evenly packed frame
     uint32_t splitFloor = 4500;       // ... and at least this much (wave run time, 10 ns units)
     int residentWaves = 0;
-    hipStream_t splitStream = nullptr;  // the split waves run beside the regular ones
-    hipEvent_t evFork = nullptr, evJoin = nullptr;
     // Host-mapped word the selection kernel writes the number of split waves to.  Read without synchronising: a stale value
     // only decides whether a frame uses split waves at all (with split = 0 the regular waves render every block).
     volatile uint32_t* hSplitWaves = nullptr;
@@ -199,17 +197,9 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
         fb.frameStart = &ctx->dSplitState->frameStart;
         if (launch.split) { fb.extraMap = ctx->dExtraMap; fb.heavyBits = ctx->dHeavyBits; }
     }
-    if (launch.split) {
-        // fork: the split waves of the heaviest blocks start first, on their own stream, and run beside the regular waves
-        RT_HIP(hipEventRecord(ctx->evFork, stream));
-        RT_HIP(hipStreamWaitEvent(ctx->splitStream, ctx->evFork, 0));
-        unsigned long long* splitClocks = waveClocks ? waveClocks + (size_t)rt::launchGridBlocks(launch) * RT_WAVE_RECORD_WORDS : nullptr;
-        RT_HIP(rt::launchRenderSplit(ctx->scene, launch, out, ids, tbuf, counters, instrumented, ctx->splitStream, splitClocks, cur, fb));
-        RT_HIP(hipEventRecord(ctx->evJoin, ctx->splitStream));
-    }
+    // with launch.split the grid starts with the split waves of the heaviest blocks (their records follow the regular ones)
     RT_HIP(rt::launchRender(ctx->scene, launch, out, ids, tbuf, counters, instrumented, stream, waveClocks,
                             plan.haveOrder ? ctx->dTileOrder : nullptr, cur, fb));
-    if (launch.split) RT_HIP(hipStreamWaitEvent(stream, ctx->evJoin, 0));
     RT_HIP(rt::launchRankTiles(cur, ctx->dTileOrder, nxt, p.ownedTiles, stream));
     // While the last selection split nothing (host hint, possibly a frame or two old), look again only now and then: the
     // block costs keep accumulating their maxima in between, and a frame that does not split saves two small launches.
@@ -302,13 +292,7 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     c->residentWaves = rt::residentRenderWaves();
     if (c->residentWaves <= 0) c->split = 0;
     if (c->split) {
-        // Default priority.  The split launch is issued before the regular one, which is enough for its waves to get their
-        // slots first.  With a high-priority stream the frame time was the same, and a process with two contexts plus an
-        // exchange stream (six streams on four hardware queues) stopped making progress on the GPU: a waiting high-priority
-        // queue kept the queue it waited for from being scheduled.
-        hipError_t se = hipStreamCreateWithFlags(&c->splitStream, hipStreamNonBlocking);
-        if (se == hipSuccess) se = hipEventCreateWithFlags(&c->evFork, hipEventDisableTiming);
-        if (se == hipSuccess) se = hipEventCreateWithFlags(&c->evJoin, hipEventDisableTiming);
+        hipError_t se = hipSuccess;
         void* hp = nullptr;
         if (se == hipSuccess && !std::getenv("RT_NO_HINT")) se = hipHostMalloc(&hp, 64, hipHostMallocMapped);
         if (se == hipSuccess && hp) {
@@ -318,7 +302,7 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
             se = hipHostGetDevicePointer(&dp, hp, 0);
             c->dSplitWaves = static_cast<uint32_t*>(dp);
         }
-        if (se != hipSuccess) { const int rc = failHip(se, "stream for split waves"); rt_destroy(c); return rc; }
+        if (se != hipSuccess) { const int rc = failHip(se, "host-visible hint for split waves"); rt_destroy(c); return rc; }
     }
     if (const char* e = std::getenv("RT_SPLIT_START")) { const int v = std::atoi(e); if (v >= 4 && v <= 1000) c->splitStartTenths = v; }
     if (const char* e = std::getenv("RT_SPLIT_FLOOR")) { const int v = std::atoi(e); if (v >= 0) c->splitFloor = (uint32_t)v; }
@@ -357,9 +341,6 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->dExtraMap) (void)hipFree(ctx->dExtraMap);
     if (ctx->dHeavyBits) (void)hipFree(ctx->dHeavyBits);
     if (ctx->dSplitState) (void)hipFree(ctx->dSplitState);
-    if (ctx->evFork) (void)hipEventDestroy(ctx->evFork);
-    if (ctx->evJoin) (void)hipEventDestroy(ctx->evJoin);
-    if (ctx->splitStream) (void)hipStreamDestroy(ctx->splitStream);
     if (ctx->hSplitWaves) (void)hipHostFree(const_cast<uint32_t*>(ctx->hSplitWaves));
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);

@@ -15,12 +15,6 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
                         unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks = nullptr,
                         const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr, BlockFeedback fb = BlockFeedback{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
 
-// The split waves of the frame's heaviest blocks (fb.extraMap), kMaxExtraWaves workgroups; meant to run concurrently with
-// launchRender of the same frame on another stream.  waveClocks, if given, receives kMaxExtraWaves records.
-hipError_t launchRenderSplit(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
-                            unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
-                            uint32_t* tileCost, BlockFeedback fb);
-
 // Block feedback between frames (see BlockFeedback): gathers the statistics of the costs in blockCost into slot `slot` of
 // `state`, chooses the blocks the next frame renders with split waves (extraMap, heavyBits, state->used[slot]) and clears
 // blockCost.  slots = waves resident on the device at once (residentRenderWaves()).  heavyBits needs blocks / 32 + 8 words.

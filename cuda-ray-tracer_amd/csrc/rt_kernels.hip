@@ -925,10 +925,10 @@ constexpr int kWavesPerTile = kWavesPerTileSide * kWavesPerTileSide;
 // Bits 0,2,4 of v -> bits 0,1,2 (one coordinate of a Z-order index).
 RT_DEV uint32_t evenBits3(uint32_t v) { return (v & 1u) | ((v >> 1) & 2u) | ((v >> 2) & 4u); }
 
-// SPLIT = false: one wave per 8x8 pixel block, one lane per pixel.  SPLIT = true: the waves listed in fb.extraMap, each
-// rendering one pixel row of one of the frame's heaviest blocks: eight lanes bring a pixel, the other 56 only help with
-// the mesh traversal.
-template <bool STATS, bool SPLIT>
+// Regular waves: one wave per 8x8 pixel block, one lane per pixel.  With P.split the grid starts with kMaxExtraWaves split
+// waves, the ones listed in fb.extraMap, each rendering one pixel row of one of the frame's heaviest blocks: eight lanes
+// bring a pixel, the other 56 only help with the mesh traversal.
+template <bool STATS>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3))) void renderKernel(DevScene sceneArg, FrameParams frameArg, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
                                                     float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
                                                     unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
@@ -939,8 +939,16 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     separateScalars<19>(S); separateScalars<0>(P);
     const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
     const unsigned long long costStart = tileCost ? __builtin_amdgcn_s_memrealtime() : 0ull;    // costs are wall time in 10 ns units
-    if (!SPLIT && fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
-    if (!SPLIT && fb.frameStart && blockIdx.x == 0 && threadIdx.x == 0) *fb.frameStart = costStart;
+    if (fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
+    if (fb.frameStart && blockIdx.x == 0 && threadIdx.x == 0) *fb.frameStart = costStart;
+    // The split waves come first in the grid: workgroups are dispatched in index order, so they get their wave slots before
+    // the regular waves of the same launch.  (Alternating groups of eight split and eight regular waves, so that the
+    // heaviest regular tiles also start at once, was slower whenever two frames are in flight: 0.197 / 0.130 / 0.097 ms
+    // against 0.158 / 0.124 / 0.095 ms for a rank's share of 1/2, 1/4, 1/8 of the frame.)
+    const uint32_t extraWaves = P.split ? (uint32_t)kMaxExtraWaves : 0u;      // a multiple of 8: the regular waves keep their XCDs
+    const uint32_t regularWaves = gridDim.x - extraWaves;
+    const bool splitWave = blockIdx.x < extraWaves;
+    const uint32_t waveIndex = splitWave ? blockIdx.x : blockIdx.x - extraWaves;    // among the waves of its kind
     // 12416 bytes per wave: twelve waves per CU (three per SIMD) fit the 160 KB of LDS.  Measured: at 12928 bytes fewer
     // waves are resident and the frame takes 7 % longer.
     __shared__ f4_t poolRays[3 * kBlockThreads];
@@ -958,16 +966,16 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     // tile sequence: the 16 waves of a tile share one L2, and every XCD gets the same mix of cheap and expensive tiles.
     uint32_t localTile, inTile, sub = 0;
     bool retire = false;
-    if (SPLIT) {
+    if (splitWave) {
         const uint32_t count = *fb.extraCount;
-        if (blockIdx.x < (count < (uint32_t)kMaxExtraWaves ? count : (uint32_t)kMaxExtraWaves)) {
-            const uint32_t e = fb.extraMap[blockIdx.x];
+        if (waveIndex < (count < (uint32_t)kMaxExtraWaves ? count : (uint32_t)kMaxExtraWaves)) {
+            const uint32_t e = fb.extraMap[waveIndex];
             const uint32_t blk = e & 0xFFFFFu;
             sub = (e >> 20) & 7u;
             localTile = blk / (uint32_t)kWavesPerTile; inTile = blk % (uint32_t)kWavesPerTile;
         } else { localTile = 0; inTile = 0; retire = true; }
     } else {
-        const uint32_t b = blockIdx.x;
+        const uint32_t b = waveIndex;
         if (P.blockOrder == 2) {
             const uint32_t xcd = b % 8u, i = b / 8u;
             localTile = (i / kWavesPerTile) * 8u + xcd;
@@ -984,9 +992,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
             if ((fb.heavyBits[blk >> 5] >> (blk & 31u)) & 1u) retire = true;      // split waves render this block
         }
     }
+    // diagnostic records: the regular waves first, then the split waves
+    const size_t recordIndex = splitWave ? (size_t)regularWaves + waveIndex : (size_t)waveIndex;
     if (retire) {
         if (STATS && waveClocks && lane == 0) {
-            for (int k = 0; k < kWaveRecordWords; k++) waveClocks[kWaveRecordWords * (size_t)blockIdx.x + k] = 0;
+            for (int k = 0; k < kWaveRecordWords; k++) waveClocks[kWaveRecordWords * recordIndex + k] = 0;
         }
         return;
     }
@@ -995,8 +1005,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     // the waves of a tile walk it in Z order (neighbours in time are neighbours on screen).  A regular wave renders the whole
     // 8x8 block, lane l = pixel (l & 7, l >> 3); a split wave renders row `sub` of the block with its first eight lanes.
     const uint32_t bx = evenBits3(inTile) * 8u, by = evenBits3(inTile >> 1) * 8u;
-    const bool pixelLane = !SPLIT || lane < 8u;
-    const uint32_t lx = bx + (lane & 7u), ly = by + (SPLIT ? sub : (lane >> 3));
+    const bool pixelLane = !splitWave || lane < 8u;
+    const uint32_t lx = bx + (lane & 7u), ly = by + (splitWave ? sub : (lane >> 3));
     const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
 
     Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0;
@@ -1040,7 +1050,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
         }
     }
     if (STATS && waveClocks && lane == 0) {      // diagnostic: when this wave started and finished, and its section sums
-        unsigned long long* rec = waveClocks + kWaveRecordWords * (size_t)blockIdx.x;
+        unsigned long long* rec = waveClocks + kWaveRecordWords * recordIndex;
         rec[0] = clockStart;
         rec[1] = __builtin_amdgcn_s_memrealtime();
         for (int k = 0; k < 16; k++) rec[2 + k] = lds.prof[k];
@@ -1051,7 +1061,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
         // little below the measured speed-up (1.65) so that a block never looks heavier split than it was unsplit, which
         // would keep a frame that does not profit from splitting in the split state.
         const uint32_t own = (uint32_t)spent + 1u;
-        const uint32_t cost = SPLIT ? own * 3u / 2u : own;
+        const uint32_t cost = splitWave ? own * 3u / 2u : own;
         atomicMax(&tileCost[localTile], cost);   // a tile is as urgent as its slowest wave
         if (fb.blockCost) atomicMax(&fb.blockCost[localTile * (uint32_t)kWavesPerTile + inTile], cost);
     }
@@ -1142,19 +1152,9 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
                         unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
                         const uint32_t* tileOrder, uint32_t* tileCost, BlockFeedback fb) {
     if (P.ownedTiles <= 0) return hipSuccess;
-    dim3 grid(launchGridBlocks(P)), block(kBlockThreads);
-    if (stats) hipLaunchKernelGGL((renderKernel<true, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
-    else hipLaunchKernelGGL((renderKernel<false, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
-    return hipGetLastError();
-}
-
-hipError_t launchRenderSplit(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
-                            unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
-                            uint32_t* tileCost, BlockFeedback fb) {
-    if (P.ownedTiles <= 0 || !P.split) return hipSuccess;
-    dim3 grid((unsigned)kMaxExtraWaves), block(kBlockThreads);
-    if (stats) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
-    else hipLaunchKernelGGL((renderKernel<false, true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, nullptr, tileCost, fb);
+    dim3 grid(launchGridBlocks(P) + (P.split ? (unsigned)kMaxExtraWaves : 0u)), block(kBlockThreads);
+    if (stats) hipLaunchKernelGGL((renderKernel<true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
+    else hipLaunchKernelGGL((renderKernel<false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
     return hipGetLastError();
 }
 
@@ -1262,7 +1262,7 @@ int residentRenderWaves() {
     int device = 0, cus = 0, perCu = 0;
     if (hipGetDevice(&device) != hipSuccess) return 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<false, false>, kBlockThreads, 0) != hipSuccess) return 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, renderKernel<false>, kBlockThreads, 0) != hipSuccess) return 0;
     return cus * perCu;
 }
 
