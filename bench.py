@@ -92,7 +92,8 @@ def main():
                          "frame overlaps the slow tail of the frame before it; 0 = 1 on one GPU (the roofline line is defined on "
                          "launches that do not overlap), 2 on several GPUs (a rank's share of a frame is as long as its heaviest "
                          "8x8 block and leaves most of the GPU idle)")
-    ap.add_argument("--tile-slots", type=int, default=4, help="several GPUs: tile buffers per rank (frames that can be between render and gather)")
+    ap.add_argument("--tile-slots", type=int, default=3, help="several GPUs: tile-buffer slots per rank (gathers that can be in flight or being filled)")
+    ap.add_argument("--frames-per-gather", type=int, default=0, help="several GPUs: consecutive frames whose tiles one gather moves (0 = 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out", type=str, default="", help="write the last frame as PNG (rank 0)")
     args = ap.parse_args()
@@ -151,7 +152,10 @@ def main():
     if tiled and world == 1 and int(os.environ.get("RT_BENCH_EMULATE_WORLD", "0")) > 1:
         share = int(os.environ["RT_BENCH_EMULATE_WORLD"])
     in_flight = args.frames_in_flight if args.frames_in_flight > 0 else (2 if share > 1 else 1)
-    if os.environ.get("RT_BENCH_OWN_STREAM", "0") == "1":     # lane 0 on a stream of its own instead of the default stream
+    if os.environ.get("RT_BENCH_OWN_STREAM", "1" if in_flight > 1 else "0") == "1":
+        # Several frames in flight: every lane on a stream of its own.  Work on the default stream does not overlap with work
+        # on the other streams (measured: a rank's share of 1/8 of the frame, two lanes: 0.184 ms per frame with lane 0 on the
+        # default stream, 0.100 ms on its own stream).
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
         stream = torch.cuda.current_stream().cuda_stream
     lanes = [(r, torch.cuda.current_stream(), frame)]
@@ -161,31 +165,35 @@ def main():
         extra.set_state(built.camera, cfg)
         lanes.append((extra, torch.cuda.Stream(device=dev), None if tiled else torch.empty(pixels * 3, dtype=torch.uint8, device=dev)))
     if tiled:
-        # several tile buffers: the gather of frame k (RCCL's own stream) overlaps the render of the frames after it; a buffer is
-        # rendered into again only when its gather has finished, so their number bounds how many frames the pipeline holds
-        slots = max(2, in_flight, args.tile_slots)
+        # A slot holds the tile buffers of `batch` consecutive frames, which one gather moves (the host cost of a collective
+        # call is about that of rendering a frame's share).  Several slots: the gather of a slot (RCCL's own stream) overlaps
+        # the render of the frames after it; a slot is rendered into again only when its gather has finished, so their number
+        # bounds how many frames the pipeline holds.
+        batch = max(1, args.frames_per_gather if args.frames_per_gather > 0 else (4 if share > 1 else 1))
+        slots = max(2, args.tile_slots)
         tile_bytes = binding.tile_buffer_bytes(w, h, share)
-        tiles = [torch.empty(tile_bytes, dtype=torch.uint8, device=dev) for _ in range(slots)]
-        gathered = [torch.zeros(tile_bytes * share, dtype=torch.uint8, device=dev) for _ in range(slots)] if rank == 0 else [None] * slots
+        slot_bytes = tile_bytes * batch
+        tiles = [torch.empty(slot_bytes, dtype=torch.uint8, device=dev) for _ in range(slots)]
+        gathered = [torch.zeros(slot_bytes * share, dtype=torch.uint8, device=dev) for _ in range(slots)] if rank == 0 else [None] * slots
         gather_list = [list(g.chunk(share))[:world] for g in gathered] if rank == 0 else [None] * slots
         if backend != "nccl":
-            host_tiles = torch.empty(tile_bytes, dtype=torch.uint8)
-            host_gathered = torch.empty(tile_bytes * world, dtype=torch.uint8) if rank == 0 else None
+            host_tiles = torch.empty(slot_bytes, dtype=torch.uint8)
+            host_gathered = torch.empty(slot_bytes * world, dtype=torch.uint8) if rank == 0 else None
             host_list = list(host_gathered.chunk(world)) if rank == 0 else None
 
     kernel_events = []
-    host_parts = [0.0, 0.0, 0.0]    # host seconds spent issuing: render, completion of the previous frame, gather
-    pending = []     # (frame slot, async gather handle) of the frame whose tiles are still in flight
+    host_parts = [0.0, 0.0, 0.0]    # host seconds spent issuing: render, completion of the previous gather, gather
+    pending = []     # (slot, frames in it, async gather handle) of the gathers still in flight
     if tiled:
-        # The exchange (gather, reassembly on rank 0) runs on a stream of its own, so that the render stream goes from
-        # frame to frame without waiting: it only waits before overwriting a tile buffer whose gather has not finished.
+        # The exchange (gather, reassembly on rank 0) runs on a stream of its own, so that the render streams go from
+        # frame to frame without waiting: they only wait before overwriting a slot whose gather has not finished.
         xs = torch.cuda.Stream(device=dev) if os.environ.get("RT_BENCH_XSTREAM", "1") == "1" else torch.cuda.current_stream()
-        rendered_ev = [torch.cuda.Event() for _ in range(slots)]
+        rendered_ev = [[torch.cuda.Event() for _ in range(batch)] for _ in range(slots)]
         free_ev = [None] * slots
 
     def finish_pending():
         while pending:
-            slot, work = pending.pop(0)
+            slot, frames, work = pending.pop(0)
             with torch.cuda.stream(xs):
                 if work is not None:
                     work.wait()                  # the exchange stream waits for the gather; the host does not
@@ -193,9 +201,15 @@ def main():
                     free_ev[slot] = torch.cuda.Event()
                 free_ev[slot].record(xs)
                 if rank == 0:
-                    r.untile_device(w, h, share, gathered[slot].data_ptr(), frame.data_ptr(), xs.cuda_stream)
+                    for j in range(frames):      # rank q's buffer of the slot's j-th frame starts at q * slot_bytes + j * tile_bytes
+                        r.untile_strided_device(w, h, share, gathered[slot].data_ptr() + j * tile_bytes, slot_bytes, frame.data_ptr(), xs.cuda_stream)
 
     step_index = [0]
+    event_period = int(os.environ.get("RT_BENCH_EVENT_PERIOD", "4"))     # tiled path: time every n-th launch with events (0 = none)
+
+    def sample_events(k):
+        return event_period > 0 and k % event_period == 0
+
 
     def step(record):
         if not tiled:
@@ -209,32 +223,32 @@ def main():
                 e1.record(s)
                 kernel_events.append((e0, e1))
             return
-        slot = step_index[0] % slots
+        slot, j = (step_index[0] // batch) % slots, step_index[0] % batch
         ctx, s, _ = lanes[step_index[0] % in_flight]
         step_index[0] += 1
         h0 = time.perf_counter()
         if free_ev[slot] is not None:
             s.wait_event(free_ev[slot])
+        record = record and sample_events(step_index[0])
         if record:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(s)
-        ctx.render_tiles_device(w, h, rank, share, tiles[slot].data_ptr(), tile_bytes, s.cuda_stream)
+        ctx.render_tiles_device(w, h, rank, share, tiles[slot].data_ptr() + j * tile_bytes, tile_bytes, s.cuda_stream)
         if record:
             e1.record(s)
             kernel_events.append((e0, e1))
-        rendered_ev[slot].record(s)
-        h1 = time.perf_counter()
-        finish_pending()                         # frame k - 1: gathered while frame k was being rendered
-        h2 = time.perf_counter()
-        host_parts[0] += h1 - h0; host_parts[1] += h2 - h1; host_parts[2] -= h2
-        try:
-            issue_gather(slot)
-        finally:
-            host_parts[2] += time.perf_counter()
+        rendered_ev[slot][j].record(s)
+        host_parts[0] += time.perf_counter() - h0
+        if j == batch - 1:
+            exchange(slot, batch)
 
-    def issue_gather(slot):
+    def exchange(slot, frames):
+        h1 = time.perf_counter()
+        finish_pending()                         # the gather before this one ran while this slot was being rendered
+        h2 = time.perf_counter()
         with torch.cuda.stream(xs):
-            xs.wait_event(rendered_ev[slot])
+            for j in range(frames):
+                xs.wait_event(rendered_ev[slot][j])
             if backend == "nccl":
                 work = dist.gather(tiles[slot], gather_list[slot], dst=0, async_op=True)
             else:
@@ -243,10 +257,14 @@ def main():
                 if rank == 0:
                     gathered[slot].copy_(host_gathered)
                 work = None
-        pending.append((slot, work))
+        pending.append((slot, frames, work))
+        host_parts[1] += h2 - h1; host_parts[2] += time.perf_counter() - h2
 
     def fence():
         if tiled:
+            if step_index[0] % batch != 0:       # a slot that is only partly filled: gather it as it is
+                exchange((step_index[0] // batch) % slots, step_index[0] % batch)
+                step_index[0] += batch - step_index[0] % batch
             finish_pending()
             if os.environ.get("RT_BENCH_DEBUG_HANG"):
                 t_end = time.perf_counter() + 5.0
@@ -254,7 +272,7 @@ def main():
                     if time.perf_counter() >= t_end:
                         break
                     time.sleep(0.01)
-                print("lanes done:", [l[1].query() for l in lanes], "xs done:", xs.query(), "rendered:", [e.query() for e in rendered_ev],
+                print("lanes done:", [l[1].query() for l in lanes], "xs done:", xs.query(), "rendered:", [[e.query() for e in evs] for evs in rendered_ev],
                       "free:", [e.query() if e is not None else None for e in free_ev], "steps issued:", step_index[0], file=sys.stderr, flush=True)
             torch.cuda.synchronize()
             dist.barrier()
@@ -273,7 +291,7 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / max(len(kernel_events), 1)
+    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / len(kernel_events) if kernel_events else elapsed * 1e3 / args.steps
 
     if rank == 0:
         ms_per_step = elapsed * 1e3 / args.steps
@@ -304,7 +322,8 @@ def main():
                        else f"config{args.config} at {w}x{h}",
                        "triangles": int(info.triangleCount), "octree_nodes": int(info.nodeCount), "rays_per_frame": rays,
                        "rays_per_pixel": rays / pixels, "tile": binding.RT_TILE,
-                       "frames_in_flight": in_flight,
+                       "frames_in_flight": in_flight, "frames_per_gather": batch if tiled else None,
+                       "launches_overlap": in_flight > 1,
                        "parallelism": ("1 GPU" if not tiled else f"1 GPU through the tile / gather / reassembly path (rehearsal, share of {share} ranks)") if world == 1 else f"image tiles over {world} GPUs, scene replicated, RCCL gather to rank 0"},
             "kernel_ms": kernel_ms, "host_issue_ms_per_step": enqueue * 1e3 / args.steps,
             "host_issue_parts_ms": {k: v * 1e3 / (args.steps + args.warmup) for k, v in zip(("render", "complete_previous", "gather"), host_parts)} if tiled else None,

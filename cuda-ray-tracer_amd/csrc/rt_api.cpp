@@ -561,6 +561,18 @@ int rt_untile_device(rt_ctx* ctx, int width, int height, int world, const void* 
     return RT_OK;
 }
 
+int rt_untile_strided_device(rt_ctx* ctx, int width, int height, int world, const void* d_gathered, size_t rank_stride_bytes, void* d_rgb,
+                             void* hip_stream) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    if (width <= 0 || height <= 0 || world <= 0) return fail(RT_ERR_INVALID, "bad frame or world size");
+    if (!d_gathered || !d_rgb) return fail(RT_ERR_INVALID, "null device buffer");
+    if (rank_stride_bytes < rt_tile_buffer_bytes(width, height, world) || rank_stride_bytes % 16 != 0)
+        return fail(RT_ERR_INVALID, "rank stride must be a multiple of 16 and hold a tile buffer");
+    RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb), width, height, world, tilesAlong(width),
+                            rank_stride_bytes, static_cast<hipStream_t>(hip_stream)));
+    return RT_OK;
+}
+
 int rt_get_scene_info(rt_ctx* ctx, rt_scene_info* info) {
     if (!ctx || !info) return fail(RT_ERR_INVALID, "null argument");
     if (!ctx->haveScene) return fail(RT_ERR_NO_SCENE, "rt_upload_scene has not been called");

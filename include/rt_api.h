@@ -112,6 +112,14 @@ int rt_render_tiles_device(rt_ctx* ctx, int width, int height, int rank, int wor
 int rt_untile_device(rt_ctx* ctx, int width, int height, int world, const void* d_gathered, void* d_rgb,
                      void* hip_stream);
 
+/*
+ * The same with the tile buffers `rank_stride_bytes` apart (at least rt_tile_buffer_bytes, a multiple of 16): for
+ * callers that gather the tiles of several frames with one collective, rank r's buffer of the frame then starts at
+ * d_gathered + r * rank_stride_bytes.  No reference counterpart.
+ */
+int rt_untile_strided_device(rt_ctx* ctx, int width, int height, int world, const void* d_gathered,
+                             size_t rank_stride_bytes, void* d_rgb, void* hip_stream);
+
 /* Ray count of the current scene/state at this resolution, from the device's own counters (blocking). */
 int rt_count_rays(rt_ctx* ctx, int width, int height, rt_frame_stats* stats);
 
