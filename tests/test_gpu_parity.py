@@ -323,3 +323,30 @@ def test_large_frame_ranked_by_cost_bins(renderer, pkg):
         rgb, st = renderer.render(w, h)
         assert np.array_equal(rgb, plain)
         assert st.rays == st0.rays
+
+
+def test_strided_untile_for_batched_gathers(renderer):
+    """Tile buffers of two frames per rank laid out as one gather of two frames delivers them (rank r's buffers at
+    r * 2 * per): the strided reassembly of either frame equals the frame rendered in one launch."""
+    import torch
+    from cuda_ray_tracer_amd import binding
+    w, h, world = 640, 360, 3
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.2)
+    built = scenes.build_scene(spec)
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    direct, _ = renderer.render(w, h)
+    per = binding.tile_buffer_bytes(w, h, world)
+    gathered = torch.zeros(per * 2 * world, dtype=torch.uint8, device="cuda:0")
+    frame = torch.zeros(w * h * 3, dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    for rank in range(world):
+        renderer.render_tiles_device(w, h, rank, world, gathered.data_ptr() + rank * 2 * per + per, per, stream)   # second frame only
+    renderer.untile_strided_device(w, h, world, gathered.data_ptr() + per, 2 * per, frame.data_ptr(), stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(frame.cpu().numpy().reshape(h, w, 3), direct)
+    renderer.untile_strided_device(w, h, world, gathered.data_ptr(), 2 * per, frame.data_ptr(), stream)              # first frame: never rendered
+    torch.cuda.synchronize()
+    assert not frame.any()
+    with pytest.raises(binding.RtError):
+        renderer.untile_strided_device(w, h, world, gathered.data_ptr(), per - 16, frame.data_ptr(), stream)
