@@ -97,6 +97,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--out", type=str, default="", help="write the last frame as PNG (rank 0)")
     args = ap.parse_args()
+    # Rank 0 prints exactly one line on stdout.  Libraries underneath write there too (RCCL prints a version banner at its
+    # first collective), so file descriptor 1 points at stderr for the rest of the run and the result goes to the saved one.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
 
     if os.environ.get("RT_BENCH_WATCHDOG"):      # diagnostic: dump the Python stacks if the run is still going after n seconds
         import faulthandler
@@ -278,6 +283,10 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if tiled and backend == "nccl":
+        # RCCL sets up its communicator and peer connections at the first collective of a kind: do that before any step
+        dist.gather(tiles[0], gather_list[0], dst=0)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         step(False)
     fence()
@@ -338,7 +347,7 @@ def main():
         if args.out:
             from PIL import Image
             Image.fromarray(frame.cpu().numpy().reshape(h, w, 3)).save(args.out)
-        print(json.dumps(out), flush=True)
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     for ctx, _, _ in lanes:
         ctx.close()
