@@ -210,7 +210,7 @@ def main():
                         r.untile_strided_device(w, h, share, gathered[slot].data_ptr() + j * tile_bytes, slot_bytes, frame.data_ptr(), xs.cuda_stream)
 
     step_index = [0]
-    event_period = int(os.environ.get("RT_BENCH_EVENT_PERIOD", "4"))     # tiled path: time every n-th launch with events (0 = none)
+    event_period = int(os.environ.get("RT_BENCH_EVENT_PERIOD", "4"))     # every n-th launch is timed with events (0 = none)
 
     def sample_events(k):
         return event_period > 0 and k % event_period == 0
@@ -219,6 +219,7 @@ def main():
     def step(record):
         if not tiled:
             ctx, s, buf = lanes[step_index[0] % in_flight]
+            record = record and sample_events(step_index[0])
             step_index[0] += 1
             if record:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
