@@ -39,13 +39,15 @@ def tile_numpy(frame, rank, world):
     return out
 
 
-def untile_numpy(gathered, width, height, world):
-    """Inverse of tile_numpy over `world` buffers laid end to end (rank order)."""
+def untile_numpy(gathered, width, height, world, rank_stride=None):
+    """Inverse of tile_numpy over `world` buffers in rank order: laid end to end, or `rank_stride` bytes apart
+    (rt_untile_strided_device: one gather moved the buffers of several frames, a rank's frames lie back to back)."""
     tx, ty = tile_grid(width, height)
     per = tile_buffer_bytes(width, height, world)
+    stride = per if rank_stride is None else rank_stride
     frame = np.zeros((height, width, 3), np.uint8)
     for rank in range(world):
-        view = np.asarray(gathered[rank * per:(rank + 1) * per]).reshape(-1, TILE, TILE, 3)
+        view = np.asarray(gathered[rank * stride:rank * stride + per]).reshape(-1, TILE, TILE, 3)
         for j, t in enumerate(owned_tiles(width, height, rank, world)):
             x0, y0 = (t % tx) * TILE, (t // tx) * TILE
             hh, ww = min(TILE, height - y0), min(TILE, width - x0)

@@ -49,6 +49,39 @@ def test_two_rank_gather_reassembles_frame(size):
     assert q.get(timeout=5) is True
 
 
+def _batch_worker(rank, world, port, w, h, frames, q):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(99)
+    batch = [rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8) for _ in range(frames)]      # same on every rank
+    per = sharding.tile_buffer_bytes(w, h, world)
+    mine = torch.from_numpy(np.concatenate([sharding.tile_numpy(f, rank, world) for f in batch]))     # a rank's frames back to back
+    gathered = sharding.gather_tiles(mine, rank, world, dist)
+    dist.barrier()
+    if rank == 0:
+        g = gathered.numpy()
+        ok = all(np.array_equal(sharding.untile_numpy(g[j * per:], w, h, world, rank_stride=frames * per), batch[j]) for j in range(frames))
+        q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_two_rank_gather_of_several_frames():
+    """One gather per batch of frames, as bench.py does on several GPUs: frame j of rank r lies at r * frames * per + j * per."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batch_worker, args=(r, 2, port, 200, 136, 3, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
+
+
 @pytest.mark.parametrize("world", [1, 2, 3, 4, 8])
 def test_layout_roundtrip_and_sizes(pkg, world):
     from cuda_ray_tracer_amd import binding
