@@ -1,3 +1,6 @@
+#!/usr/bin/env python3
+"""Prints a window of consecutive kernels (start, duration, queue) from the middle of a rocprofv3 --kernel-trace CSV.
+Usage: python tools/trace_window.py <kernel_trace.csv> [rows]"""
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
