@@ -103,9 +103,12 @@ def main():
     result_fd = os.dup(1)
     os.dup2(2, 1)
 
-    if os.environ.get("RT_BENCH_WATCHDOG"):      # diagnostic: dump the Python stacks if the run is still going after n seconds
+    # A rank that is still running after this many seconds dumps its Python stacks and exits, so that a stalled exchange ends
+    # the job instead of holding the node (several ranks: 600 s unless RT_BENCH_WATCHDOG says otherwise; 0 = never).
+    watchdog = float(os.environ.get("RT_BENCH_WATCHDOG", "600" if int(os.environ.get("WORLD_SIZE", "1")) > 1 else "0"))
+    if watchdog > 0:
         import faulthandler
-        faulthandler.dump_traceback_later(float(os.environ["RT_BENCH_WATCHDOG"]), exit=True)
+        faulthandler.dump_traceback_later(watchdog, exit=True)
     import torch
     import torch.distributed as dist
 
