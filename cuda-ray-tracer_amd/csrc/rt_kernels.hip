@@ -892,16 +892,19 @@ template <int pointers, typename T>
 RT_DEV void separateScalars(T& v) {
     static_assert(sizeof(T) % 4 == 0 && sizeof(T) >= 8 * (size_t)pointers, "struct of pointers followed by 32-bit fields");
     constexpr int words = (int)((sizeof(T) - 8 * (size_t)pointers) / 4);
-    unsigned long long p[pointers > 0 ? pointers : 1];
-    uint32_t w[words > 0 ? words : 1];
-    __builtin_memcpy(p, &v, 8 * (size_t)pointers);
-    __builtin_memcpy(w, reinterpret_cast<const char*>(&v) + 8 * (size_t)pointers, 4 * (size_t)words);
+    typedef const __attribute__((address_space(1))) char* GlobalPtr;
+    // The pointers come back from the asm statement as integers; converting them to pointers into global memory (and from
+    // there to the generic pointers the struct holds) keeps the loads through them global loads instead of flat ones.
+    const char** ptrs = reinterpret_cast<const char**>(&v);
 #pragma unroll
-    for (int i = 0; i < pointers; i++) { unsigned long long q; asm volatile("s_mov_b64 %0, %1" : "=s"(q) : "s"(p[i])); p[i] = q; }
+    for (int i = 0; i < pointers; i++) {
+        unsigned long long in = reinterpret_cast<unsigned long long>(ptrs[i]), q;
+        asm volatile("s_mov_b64 %0, %1" : "=s"(q) : "s"(in));
+        ptrs[i] = (const char*)(GlobalPtr)q;
+    }
+    uint32_t* w = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(&v) + 8 * (size_t)pointers);
 #pragma unroll
     for (int i = 0; i < words; i++) { uint32_t q; asm volatile("s_mov_b32 %0, %1" : "=s"(q) : "s"(w[i])); w[i] = q; }
-    __builtin_memcpy(&v, p, 8 * (size_t)pointers);
-    __builtin_memcpy(reinterpret_cast<char*>(&v) + 8 * (size_t)pointers, w, 4 * (size_t)words);
 }
 
 RT_DEV V3 rasterToCameraSpace(const FrameParams& P, float x, float y) {
