@@ -564,7 +564,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                     if (cand < bk) {
                         atomicMin(&lds.bestKey[owner], cand);
                         // every lane of this turn has applied its minimum by now: only the lane that holds it sees its own value
-                        if (*(volatile unsigned long long*)&lds.bestKey[owner] == cand) lds.bestRec[owner] = record;
+                        if (__hip_atomic_load(&lds.bestKey[owner], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) == cand) lds.bestRec[owner] = record;
                     }
                 };
                 testTriangle(A0, B0, C0, first);
