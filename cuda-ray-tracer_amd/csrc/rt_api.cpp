@@ -68,6 +68,7 @@ struct rt_ctx {
     rt::F4 plane0Mat0{}; bool hasPlane0 = false;
     int blockOrder = 2;
     int nodePoolEntries = 0;          // 0 = the kernel's compiled capacity
+    int leadWaves = 2048;             // regular waves ahead of the split waves in the grid (RT_LEAD_WAVES; measured best of 0 .. all)
     int traversal = (int)(rt::kTravDirectStart | rt::kTravExpandSiblings | (8u << 8));   // kTrav* bits | expansion limit / 8 << 8 (RT_TRAV overrides)
     // Cost-ordered dispatch: per-tile cost of the previous frame and the order derived from it (device, fixed capacity
     // so that the stream entry points never allocate).  orderKey identifies the frame geometry the order belongs to.
@@ -137,6 +138,7 @@ rt::FrameParams frameFor(const rt_ctx* ctx, int width, int height, int rank, int
     p.blockOrder = ctx->blockOrder;
     p.nodePoolEntries = ctx->nodePoolEntries;
     p.traversal = ctx->traversal;
+    p.leadWaves = ctx->leadWaves;
     p.split = 0;
     return p;
 }
@@ -286,6 +288,7 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     if (const char* e = std::getenv("RT_COST_ORDER")) c->costOrdering = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_NODE_POOL")) c->nodePoolEntries = std::atoi(e);    // tests: forces the traversal's low-room path
     if (const char* e = std::getenv("RT_TRAV")) c->traversal = std::atoi(e);
+    if (const char* e = std::getenv("RT_LEAD_WAVES")) { const int v = std::atoi(e); if (v >= 0) c->leadWaves = (v + 7) / 8 * 8; }
     if (const char* e = std::getenv("RT_DEVICE_BUILD")) c->forceDeviceBuild = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_SPLIT")) c->split = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RT_SPLIT_RATIO")) { const int v = std::atoi(e); if (v >= 0 && v <= 65536) c->splitRatio256 = v; }

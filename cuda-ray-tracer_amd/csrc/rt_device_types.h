@@ -98,6 +98,7 @@ struct FrameParams {
     int32_t blockOrder;        // workgroup -> tile mapping: 0 tile by tile, 2 tiles interleaved over the XCDs
     int32_t nodePoolEntries;   // capacity of the traversal's pool of pending children that a wave may use (96 .. the compiled size; smaller values only serve tests)
     int32_t traversal;         // kTrav* bits; bits 8-15: sibling expansion applies while the pool holds at most 8 x this many entries
+    int32_t leadWaves;         // with split: this many regular waves (a multiple of 8) come before the split waves in the grid
     int32_t split;             // 1: the grid starts with kMaxExtraWaves split waves for the heaviest blocks (BlockFeedback::extraMap)
     float camPos[3], camUp[3], camRight[3], camDir[3], fovFactor;
     float eyeDir[3];           // camPos / length(camPos) in float, component by component (the view vector of the specular term)

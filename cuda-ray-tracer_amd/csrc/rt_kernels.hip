@@ -944,14 +944,18 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     const unsigned long long costStart = tileCost ? __builtin_amdgcn_s_memrealtime() : 0ull;    // costs are wall time in 10 ns units
     if (fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
     if (fb.frameStart && blockIdx.x == 0 && threadIdx.x == 0) *fb.frameStart = costStart;
-    // The split waves come first in the grid: workgroups are dispatched in index order, so they get their wave slots before
-    // the regular waves of the same launch.  (Alternating groups of eight split and eight regular waves, so that the
-    // heaviest regular tiles also start at once, was slower whenever two frames are in flight: 0.197 / 0.130 / 0.097 ms
-    // against 0.158 / 0.124 / 0.095 ms for a rank's share of 1/2, 1/4, 1/8 of the frame.)
+    // Grid order with splitting: the regular waves of the heaviest unsplit tiles (the first P.leadWaves waves in tile order,
+    // nearly as long as the split blocks), then the split waves, then the other regular waves; workgroups are dispatched in
+    // index order.  Share of 1/2, 1/4, 1/8 of the 1080p benchmark frame, one frame in flight: 0.244 / 0.228 / 0.168 ms with
+    // the split waves first, 0.187 / 0.162 / 0.142 ms with 2048 regular waves ahead of them, 0.254 / 0.197 / 0.143 ms with
+    // all of them ahead; two frames in flight: 0.151 / 0.118 / 0.090 against 0.153 / 0.111 / 0.080 ms.  (Alternating groups
+    // of eight split and eight regular waves: 0.273 / 0.211 / 0.160 ms.)
     const uint32_t extraWaves = P.split ? (uint32_t)kMaxExtraWaves : 0u;      // a multiple of 8: the regular waves keep their XCDs
     const uint32_t regularWaves = gridDim.x - extraWaves;
-    const bool splitWave = blockIdx.x < extraWaves;
-    const uint32_t waveIndex = splitWave ? blockIdx.x : blockIdx.x - extraWaves;    // among the waves of its kind
+    // ahead of the split waves: the regular waves of the heaviest unsplit tiles (tile order), which are nearly as long
+    const uint32_t lead = extraWaves ? ((uint32_t)P.leadWaves < regularWaves ? (uint32_t)P.leadWaves : regularWaves) : 0u;
+    const bool splitWave = blockIdx.x >= lead && blockIdx.x < lead + extraWaves;
+    const uint32_t waveIndex = blockIdx.x < lead ? blockIdx.x : blockIdx.x - (splitWave ? lead : extraWaves);    // among the waves of its kind
     // 12416 bytes per wave: twelve waves per CU (three per SIMD) fit the 160 KB of LDS.  Measured: at 12928 bytes fewer
     // waves are resident and the frame takes 7 % longer.
     __shared__ f4_t poolRays[3 * kBlockThreads];
