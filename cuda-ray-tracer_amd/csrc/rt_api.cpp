@@ -85,8 +85,8 @@ struct rt_ctx {
     int splitSlot = 0;                // slot of dSplitState the next selection writes
     int framesSinceSelection = 0;     // while nothing is split the selection only runs every kIdleSelectionPeriod-th frame
     int split = 1;                    // 0 disables splitting
-    int splitRatio256 = 256;          // a block is split if it costs more than this share (in 1/256) of the evenly spread frame time
-    int splitStartTenths = 13;        // splitting starts when the heaviest block exceeds this many tenths of the evenly packed frame
+    int splitRatio256 = 512;          // a block is split if it costs more than this share (in 1/256) of the evenly spread frame time
+    int splitStartTenths = 16;        // splitting starts when the heaviest block exceeds this many tenths of the evenly packed frame
     uint32_t splitFloor = 4500;       // ... and at least this much (wave run time, 10 ns units)
     int residentWaves = 0;
     // Host-mapped word the selection kernel writes the number of split waves to.  Read without synchronising: a stale value

@@ -1190,8 +1190,8 @@ __global__ __launch_bounds__(256) void blockStatsKernel(const uint32_t* __restri
 // wave slots for 8 x kSplitGainDen / kSplitGainNum times the block's cost; the frame takes max(T, maxCost x Den / Num,
 // 1.25 x (sum of costs + extra occupancy) / slots) - the 1.25 is how far a real frame stays behind perfectly even packing.  T runs over the lower
 // edges of the top cost bins.  Nothing is split unless the model promises a frame at least 10 % shorter and the frame is
-// clearly limited by its heaviest block: that block alone must take more than 1.3 times the evenly packed frame to start
-// splitting, 1.0 times to carry on (the costs of split blocks are estimates; without the band a frame near the limit
+// clearly limited by its heaviest block: that block alone must take more than startTenths / 10 (1.6) times the evenly packed frame to start
+// splitting, 0.3 less to carry on (the costs of split blocks are estimates; without the band a frame near the limit
 // would flip every other frame).  In practice a GPU that renders a whole 1080p frame is limited by the sum of the work
 // and splits nothing, while a rank that renders a fraction of the tiles is limited by its heaviest block and splits a
 // few hundred.  ratio256 / 256 scales the weight of the extra occupancy; 0 splits whatever fits (test mode).
