@@ -1,10 +1,30 @@
 #include "OBJ_Loader.h"
 
+#include <charconv>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <sstream>
+
+namespace {
+
+// One float from the text at q, as strtof reads it (leading blanks, optional '+'), and q moved past it; q unmoved if
+// there is none.  std::from_chars is several times faster than strtof and rounds the same way (both are correctly
+// rounded); forms it does not take (hexadecimal, "inf", "nan") go to strtof.
+inline float readFloat(char*& q) {
+    char* s = q;
+    while (*s == ' ' || *s == '\t') s++;
+    const char* digits = (*s == '+') ? s + 1 : s;
+    const char* end = digits;
+    while (*end && *end != ' ' && *end != '\t' && *end != '\r' && *end != '\n' && *end != '/') end++;
+    float v = 0.0f;
+    const std::from_chars_result r = std::from_chars(digits, end, v);
+    if (r.ec == std::errc() && r.ptr == end && !(*s == '+' && *digits == '-')) { q = const_cast<char*>(end); return v; }
+    return std::strtof(q, &q);
+}
+
+}  // namespace
 
 namespace objl {
 
@@ -108,9 +128,13 @@ bool Loader::LoadFile(std::string Path) {
     if (Path.size() < 4 || Path.substr(Path.size() - 4) != ".obj") return false;
     std::ifstream file(Path, std::ios::binary);
     if (!file.is_open()) return false;
-    std::stringstream buffer;
-    buffer << file.rdbuf();
-    const std::string text = buffer.str();
+    std::string text;
+    file.seekg(0, std::ios::end);
+    const std::streamoff bytes = file.tellg();
+    if (bytes < 0) return false;
+    text.resize((size_t)bytes);
+    file.seekg(0, std::ios::beg);
+    if (bytes > 0 && !file.read(&text[0], bytes)) return false;
 
     LoadedMeshes.clear(); LoadedVertices.clear(); LoadedIndices.clear();
 
@@ -133,19 +157,21 @@ bool Loader::LoadFile(std::string Path) {
         meshIndexCount = 0;
     };
 
-    std::string line;
+    // lines are cut in place: the line break (and a carriage return before it) becomes the terminator the number parsers need
     size_t pos = 0;
     while (pos < text.size()) {
         size_t eol = text.find('\n', pos);
         if (eol == std::string::npos) eol = text.size();
-        line.assign(text, pos, eol - pos);
+        char* const line = &text[pos];
+        size_t lineLength = eol - pos;
+        if (eol < text.size()) text[eol] = '\0';       // at the end of the text the string's own terminator follows
         pos = eol + 1;
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        const char* p = skipBlank(line.c_str());
+        if (lineLength != 0 && line[lineLength - 1] == '\r') line[--lineLength] = '\0';
+        const char* p = skipBlank(line);
         const char* kwEnd = skipToken(p);
 
         const bool isGroup = keywordIs(p, kwEnd, "o") || keywordIs(p, kwEnd, "g");
-        if (isGroup || (!line.empty() && line[0] == 'g')) {
+        if (isGroup || (lineLength != 0 && line[0] == 'g')) {
             const std::string newName = isGroup ? restOfLine(kwEnd) : std::string("unnamed");
             if (!listening) {
                 listening = true;
@@ -160,17 +186,17 @@ bool Loader::LoadFile(std::string Path) {
         if (keywordIs(p, kwEnd, "v")) {
             char* q = const_cast<char*>(kwEnd);
             Vector3 v;
-            v.X = std::strtof(q, &q); v.Y = std::strtof(q, &q); v.Z = std::strtof(q, &q);
+            v.X = readFloat(q); v.Y = readFloat(q); v.Z = readFloat(q);
             positions.push_back(v);
         } else if (keywordIs(p, kwEnd, "vt")) {
             char* q = const_cast<char*>(kwEnd);
             Vector2 v;
-            v.X = std::strtof(q, &q); v.Y = std::strtof(q, &q);
+            v.X = readFloat(q); v.Y = readFloat(q);
             texcoords.push_back(v);
         } else if (keywordIs(p, kwEnd, "vn")) {
             char* q = const_cast<char*>(kwEnd);
             Vector3 v;
-            v.X = std::strtof(q, &q); v.Y = std::strtof(q, &q); v.Z = std::strtof(q, &q);
+            v.X = readFloat(q); v.Y = readFloat(q); v.Z = readFloat(q);
             normals.push_back(v);
         } else if (keywordIs(p, kwEnd, "f")) {
             corners.clear();
