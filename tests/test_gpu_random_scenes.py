@@ -58,7 +58,7 @@ def random_scene(seed):
     return spec, cfg
 
 
-@pytest.mark.parametrize("seed", list(range(12)))
+@pytest.mark.parametrize("seed", list(range(48)))
 def test_random_scene_matches_the_oracle(renderer, oracle, seed):
     spec, cfg = random_scene(1000 + seed)
     w, h = 224, 126
