@@ -287,6 +287,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # A context orders its tiles (and chooses the blocks to split) from the costs its previous frames recorded: a few frames per
+    # context bring that feedback to its steady state before the warm-up steps the caller asked for.
+    for ctx, s, buf in lanes:
+        for _ in range(8):
+            if tiled:
+                ctx.render_tiles_device(w, h, rank, share, tiles[0].data_ptr(), tile_bytes, s.cuda_stream)
+            else:
+                ctx.render_device(w, h, buf.data_ptr(), s.cuda_stream)
+    torch.cuda.synchronize()
     if tiled and backend == "nccl":
         # RCCL sets up its communicator and peer connections at the first collective of a kind: do that before any step
         dist.gather(tiles[0], gather_list[0], dst=0)
