@@ -109,6 +109,7 @@ void freeScene(rt_ctx* c) {
 }
 
 constexpr int kIdleSelectionPeriod = 8;
+constexpr int kActiveSelectionPeriod = 2;
 constexpr int kMaxOrderedTiles = 1 << 16;   // frames with more tiles per rank are rendered in plain tile order
 
 int tilesAlong(int pixels) { return (pixels + RT_TILE - 1) / RT_TILE; }
@@ -206,7 +207,10 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
     // While the last selection split nothing (host hint, possibly a frame or two old), look again only now and then: the
     // block costs keep accumulating their maxima in between, and a frame that does not split saves two small launches.
     const bool idle = !launch.split && ctx->hSplitWaves && *ctx->hSplitWaves == 0u;
-    if (feedback && idle && ++ctx->framesSinceSelection < kIdleSelectionPeriod && plan.haveOrder) {
+    // ... and while blocks are split, every second frame: the choice changes slowly, the costs keep their maxima, and the two
+    // launches are 7 % of the time a rank needs for an eighth of the 1080p frame (RT_SELECT_PERIOD overrides).
+    static const int activePeriod = std::getenv("RT_SELECT_PERIOD") ? std::atoi(std::getenv("RT_SELECT_PERIOD")) : kActiveSelectionPeriod;
+    if (feedback && ++ctx->framesSinceSelection < (idle ? kIdleSelectionPeriod : activePeriod) && plan.haveOrder) {
         // nothing to do this frame
     } else if (feedback) {
         ctx->framesSinceSelection = 0;
