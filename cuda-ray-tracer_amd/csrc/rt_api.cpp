@@ -3,6 +3,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -66,6 +67,8 @@ struct rt_ctx {
     // host copies of the small tables that rt_update_frame_state may rewrite
     rt::F4 sphere0Geom{}; bool hasSphere0 = false;
     rt::F4 plane0Mat0{}; bool hasPlane0 = false;
+    float meshLo[3] = {0, 0, 0}, meshHi[3] = {0, 0, 0}; bool haveMeshBounds = false;   // bounds of every reachable triangle
+    bool sphere0Dirty = false, plane0Dirty = false;   // the device tables still hold older values: the next launch patches them first
     int blockOrder = 2;
     int nodePoolEntries = 0;          // 0 = the kernel's compiled capacity
     int leadWaves = 2048;             // regular waves ahead of the split waves in the grid (RT_LEAD_WAVES; measured best of 0 .. all)
@@ -126,6 +129,20 @@ int checkFrameArgs(rt_ctx* ctx, int width, int height) {
     if (!ctx->haveState) return fail(RT_ERR_NO_STATE, "rt_update_frame_state has not been called");
     if (ctx->frame.meshMode == rt::kMeshEightBoxes && !ctx->chunksSequential)
         return fail(RT_ERR_INVALID, "eightBoundingBoxes needs models whose chunk boxes list their triangles in file order");
+    if (ctx->frame.meshMode == rt::kMeshNoBox && ctx->haveMeshBounds) {
+        // Without a bounding-box gate Model::hit also accepts hits behind the ray origin at any distance (Model.cpp:318-356),
+        // and the padding of the octree boxes covers the traversal's rounding error only up to about 3000 units between a ray
+        // origin and a mesh.  Primary and reflection rays start within 999 units of the camera.
+        float d2 = 0.0f;
+        for (int a = 0; a < 3; a++) {
+            const float c = ctx->frame.camPos[a];
+            const float d = c < ctx->meshLo[a] ? ctx->meshLo[a] - c : (c > ctx->meshHi[a] ? c - ctx->meshHi[a] : 0.0f);
+            d2 += d * d;
+        }
+        if (!(d2 <= 1500.0f * 1500.0f)) return fail(RT_ERR_INVALID, "boundingBox = false: the camera must stay within 1500 units of the meshes");
+    }
+    // every entry point launches on the context's own device, whatever device the calling thread had current
+    RT_HIP(hipSetDevice(ctx->device));
     return RT_OK;
 }
 
@@ -154,7 +171,11 @@ DispatchPlan planDispatch(const rt_ctx* ctx, const rt::FrameParams& p) {
     DispatchPlan d;
     d.p = p;
     d.ordered = ctx->costOrdering && p.blockOrder == 2 && p.ownedTiles > 0 && p.ownedTiles <= kMaxOrderedTiles;
-    d.key = ((long long)p.width << 40) ^ ((long long)p.height << 20) ^ ((long long)p.world << 8) ^ (long long)p.rank;
+    // frame geometry the tile order belongs to: 16 bits each of width and height, 12 bits each of world and rank (wider
+    // values only cost a needless restart of the feedback), and the tile count the order list was sized for
+    d.key = ((long long)(p.width & 0xffff) << 47) | ((long long)(p.height & 0xffff) << 31) | ((long long)(p.world & 0xfff) << 19) |
+            ((long long)(p.rank & 0xfff) << 7);
+    d.key ^= (long long)p.ownedTiles * 0x9E3779B1LL;
     d.haveOrder = d.ordered && ctx->orderKey == d.key;
     return d;
 }
@@ -173,6 +194,11 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
                   bool instrumented, hipStream_t stream, unsigned long long* waveClocks = nullptr) {
     const DispatchPlan plan = planDispatch(ctx, frame);
     const rt::FrameParams& p = plan.p;
+    if (ctx->sphere0Dirty || ctx->plane0Dirty) {
+        RT_HIP(rt::launchPatchTables(ctx->sphere0Dirty ? const_cast<rt::F4*>(ctx->scene.sphGeom) : nullptr, ctx->sphere0Geom,
+                                     ctx->plane0Dirty ? const_cast<rt::F4*>(ctx->scene.plnMat) : nullptr, ctx->plane0Mat0, stream));
+        ctx->sphere0Dirty = ctx->plane0Dirty = false;
+    }
     if (!plan.ordered) {
         RT_HIP(rt::launchRender(ctx->scene, p, out, ids, tbuf, counters, instrumented, stream, waveClocks));
         return RT_OK;
@@ -291,7 +317,7 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     if (const char* e = std::getenv("RT_BLOCK_ORDER")) c->blockOrder = std::atoi(e);   // experiment switches
     if (const char* e = std::getenv("RT_COST_ORDER")) c->costOrdering = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_NODE_POOL")) c->nodePoolEntries = std::atoi(e);    // tests: forces the traversal's low-room path
-    if (const char* e = std::getenv("RT_TRAV")) c->traversal = std::atoi(e);
+    if (const char* e = std::getenv("RT_TRAV")) c->traversal = std::atoi(e) & 0xffff;   // the kernel caps the expansion limit at its pool size
     if (const char* e = std::getenv("RT_LEAD_WAVES")) { const int v = std::atoi(e); if (v >= 0) c->leadWaves = (v + 7) / 8 * 8; }
     if (const char* e = std::getenv("RT_DEVICE_BUILD")) c->forceDeviceBuild = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_SPLIT")) c->split = std::atoi(e) != 0 ? 1 : 0;
@@ -315,7 +341,7 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     if (const char* e = std::getenv("RT_SPLIT_FLOOR")) { const int v = std::atoi(e); if (v >= 0) c->splitFloor = (uint32_t)v; }
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, sizeof(unsigned long long) * rt::kCntCount);
-    if (e != hipSuccess) { delete c; return failHip(e, "hipMalloc(counters)"); }
+    if (e != hipSuccess) { const int rc = failHip(e, "hipMalloc(counters)"); rt_destroy(c); return rc; }
     c->dCounters = static_cast<unsigned long long*>(p);
     void* q = nullptr;
     e = hipMalloc(&q, sizeof(uint32_t) * kMaxOrderedTiles * 2);
@@ -410,6 +436,18 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
     ctx->chunksSequential = flat.chunksSequential;
     ctx->hasSphere0 = !flat.sphGeom.empty();
     if (ctx->hasSphere0) ctx->sphere0Geom = flat.sphGeom[0];
+    ctx->sphere0Dirty = ctx->plane0Dirty = false;
+    ctx->haveMeshBounds = false;
+    for (size_t i = 0; i < flat.mdlTightMin.size(); i++) {
+        if (flat.mdlInfo[4 * i] == rt::kNoRoot) continue;
+        const float lo[3] = {flat.mdlTightMin[i].x, flat.mdlTightMin[i].y, flat.mdlTightMin[i].z};
+        const float hi[3] = {flat.mdlTightMax[i].x, flat.mdlTightMax[i].y, flat.mdlTightMax[i].z};
+        for (int a = 0; a < 3; a++) {
+            ctx->meshLo[a] = ctx->haveMeshBounds ? std::min(ctx->meshLo[a], lo[a]) : lo[a];
+            ctx->meshHi[a] = ctx->haveMeshBounds ? std::max(ctx->meshHi[a], hi[a]) : hi[a];
+        }
+        ctx->haveMeshBounds = true;
+    }
     ctx->hasPlane0 = !flat.plnMat.empty();
     if (ctx->hasPlane0) ctx->plane0Mat0 = flat.plnMat[0];
 
@@ -478,18 +516,21 @@ int rt_update_frame_state(rt_ctx* ctx, const rt_camera* cam, const rt_config* cf
     f |= rt::kCfgModelsVisible;
     p.flags = f;
 
-    if (dyn && ctx->haveScene) {
-        RT_HIP(hipSetDevice(ctx->device));
+    // The dynamic block only rewrites host copies here.  The light travels by value with every launch (DevScene::lightPos);
+    // sphere 0 and plane 0's ambient colour are written into the device tables by a one-thread kernel that the next render
+    // call enqueues on its own stream ahead of the frame, so a frame that is still running keeps the values it was issued with.
+    if (dyn && !ctx->haveScene) return fail(RT_ERR_NO_SCENE, "rt_update_frame_state: a dynamic block needs an uploaded scene");
+    if (dyn) {
         if (dyn->setLight) {
             ctx->scene.lightPos[0] = dyn->lightPosition.x; ctx->scene.lightPos[1] = dyn->lightPosition.y; ctx->scene.lightPos[2] = dyn->lightPosition.z;
         }
         if (dyn->setSphere0 && ctx->hasSphere0) {
             ctx->sphere0Geom = rt::F4{dyn->sphere0Position.x, dyn->sphere0Position.y, dyn->sphere0Position.z, dyn->sphere0Radius};
-            RT_HIP(hipMemcpy(const_cast<rt::F4*>(ctx->scene.sphGeom), &ctx->sphere0Geom, sizeof(rt::F4), hipMemcpyHostToDevice));
+            ctx->sphere0Dirty = true;
         }
         if (dyn->setPlane0 && ctx->hasPlane0) {
             ctx->plane0Mat0.x = dyn->plane0AmbientColour.x; ctx->plane0Mat0.y = dyn->plane0AmbientColour.y; ctx->plane0Mat0.z = dyn->plane0AmbientColour.z;
-            RT_HIP(hipMemcpy(const_cast<rt::F4*>(ctx->scene.plnMat), &ctx->plane0Mat0, sizeof(rt::F4), hipMemcpyHostToDevice));
+            ctx->plane0Dirty = true;
         }
     }
     ctx->haveState = true;
@@ -563,6 +604,7 @@ int rt_untile_device(rt_ctx* ctx, int width, int height, int world, const void* 
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
     if (width <= 0 || height <= 0 || world <= 0) return fail(RT_ERR_INVALID, "bad frame or world size");
     if (!d_gathered || !d_rgb) return fail(RT_ERR_INVALID, "null device buffer");
+    RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb), width, height, world, tilesAlong(width),
                             rt_tile_buffer_bytes(width, height, world), static_cast<hipStream_t>(hip_stream)));
     return RT_OK;
@@ -575,6 +617,7 @@ int rt_untile_strided_device(rt_ctx* ctx, int width, int height, int world, cons
     if (!d_gathered || !d_rgb) return fail(RT_ERR_INVALID, "null device buffer");
     if (rank_stride_bytes < rt_tile_buffer_bytes(width, height, world) || rank_stride_bytes % 16 != 0)
         return fail(RT_ERR_INVALID, "rank stride must be a multiple of 16 and hold a tile buffer");
+    RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb), width, height, world, tilesAlong(width),
                             rank_stride_bytes, static_cast<hipStream_t>(hip_stream)));
     return RT_OK;

@@ -28,6 +28,9 @@ hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, uint32_t* clea
 // Workgroups (= waves) launchRender starts for these parameters.
 unsigned launchGridBlocks(const FrameParams& P);
 
+// Enqueues the rewrite of sphere 0's geometry record and / or plane 0's ambient colour (null pointer = leave alone).
+hipError_t launchPatchTables(F4* sphGeom0, F4 sphere0, F4* plnMat0, F4 plane0Mat0, hipStream_t stream);
+
 hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX,
                         size_t perRankBytes, hipStream_t stream);
 

@@ -234,16 +234,18 @@ RT_DEV uint32_t permuteOctants(uint32_t m, uint32_t oct) {
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
 
-// Per-ray constants of the approximate slab tests: rd = 1/d (v_rcp_f32, 1 ulp), ord = o * rd.
+// Per-ray constants of the approximate slab tests: rd = 1/d (v_rcp_f32, 1 ulp) and the origin.  A plane at coordinate p
+// lies at ray parameter (p - o) * rd: the subtraction comes first, so the rounding error is relative to the distance between
+// the ray origin and the plane, wherever in the world the two are.
 struct SlabRay {
-    V3 rd, ord;
+    V3 rd, o;
     uint32_t oct;            // bit a set: the ray travels towards -a (sign bit of d, so that -0 pairs with rd = -inf)
 };
 
 RT_DEV SlabRay makeSlabRay(V3 o, V3 d) {
     SlabRay r;
     r.rd = mk(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y), __builtin_amdgcn_rcpf(d.z));
-    r.ord = mk(o.x * r.rd.x, o.y * r.rd.y, o.z * r.rd.z);
+    r.o = o;
     r.oct = (fbits(d.x) >> 31) | ((fbits(d.y) >> 31) << 1) | ((fbits(d.z) >> 31) << 2);
     return r;
 }
@@ -278,13 +280,14 @@ RT_DEV uint32_t testFour(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uin
 // Conservative slab test of the eight child boxes of one node (head = the node's first 16 bytes); returns the bit mask
 // of slots whose decoded box overlaps [tmin, tmax] along the ray (tmin is 0, or -inf for the mesh mode without a t > 0
 // test).  Bits of unused slots are meaningless.  Conservative because the host pads every child box by more than the
-// worst-case error of the fma / reciprocal form for coordinates and ray origins up to a few thousand units
-// (rt_scene.cpp) before rounding it outwards onto the node's grid.
+// worst-case error of this form (rt_scene.cpp) before rounding it outwards onto the node's grid: a plane's parameter
+// carries five roundings (subtraction, product, reciprocal 1 ulp, fma), each relative to the distance between the ray
+// origin and the node - under 3e-7 of that distance on the plane's axis, and a hit that counts is nearer than 999.
 RT_DEV uint32_t testChildren(const F4* node, u4_t head, const SlabRay& r, float tmin, float tmax) {
     const u4_t qx = *reinterpret_cast<const u4_t*>(node + 2), qy = *reinterpret_cast<const u4_t*>(node + 3), qz = *reinterpret_cast<const u4_t*>(node + 4);
-    // plane at origin + q * step  ->  parameter (origin + q * step - o) / d = q * (step * rd) + (origin * rd - o * rd)
+    // plane at origin + q * step  ->  parameter (origin + q * step - o) / d = q * (step * rd) + (origin - o) * rd
     const V3 s = mk(ubits((head.w & 0xffu) << 23) * r.rd.x, ubits(((head.w >> 8) & 0xffu) << 23) * r.rd.y, ubits(((head.w >> 16) & 0xffu) << 23) * r.rd.z);
-    const V3 b = mk(__builtin_fmaf(ubits(head.x), r.rd.x, -r.ord.x), __builtin_fmaf(ubits(head.y), r.rd.y, -r.ord.y), __builtin_fmaf(ubits(head.z), r.rd.z, -r.ord.z));
+    const V3 b = mk((ubits(head.x) - r.o.x) * r.rd.x, (ubits(head.y) - r.o.y) * r.rd.y, (ubits(head.z) - r.o.z) * r.rd.z);
     // the ray enters through the low planes on axes it travels along in the positive direction, the high planes otherwise
     const bool px = !(r.oct & 1u), py = !(r.oct & 2u), pz = !(r.oct & 4u);
     uint32_t lo4 = testFour(px ? qx.x : qx.z, py ? qy.x : qy.z, pz ? qz.x : qz.z, px ? qx.z : qx.x, py ? qy.z : qy.x, pz ? qz.z : qz.x, s, b, tmin, tmax);
@@ -293,9 +296,9 @@ RT_DEV uint32_t testChildren(const F4* node, u4_t head, const SlabRay& r, float 
 }
 
 RT_DEV bool tightBoxHit(V3 lo, V3 hi, const SlabRay& r, float tmin, float tmax) {
-    float ax = __builtin_fmaf(lo.x, r.rd.x, -r.ord.x), bx = __builtin_fmaf(hi.x, r.rd.x, -r.ord.x);
-    float ay = __builtin_fmaf(lo.y, r.rd.y, -r.ord.y), by = __builtin_fmaf(hi.y, r.rd.y, -r.ord.y);
-    float az = __builtin_fmaf(lo.z, r.rd.z, -r.ord.z), bz = __builtin_fmaf(hi.z, r.rd.z, -r.ord.z);
+    float ax = (lo.x - r.o.x) * r.rd.x, bx = (hi.x - r.o.x) * r.rd.x;
+    float ay = (lo.y - r.o.y) * r.rd.y, by = (hi.y - r.o.y) * r.rd.y;
+    float az = (lo.z - r.o.z) * r.rd.z, bz = (hi.z - r.o.z) * r.rd.z;
     float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
     float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
     return tn <= tf;
@@ -438,7 +441,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 const f4_t ro4 = lds.rayO[owner], rr4 = lds.rayR[owner];
                 const V3 ro = xyz(ro4);
                 SlabRay sr;
-                sr.rd = xyz(rr4); sr.ord = mk(ro.x * sr.rd.x, ro.y * sr.rd.y, ro.z * sr.rd.z); sr.oct = fbits(rr4.w);
+                sr.rd = xyz(rr4); sr.o = ro; sr.oct = fbits(rr4.w);
                 oct = sr.oct;
                 const uint32_t c = (uint32_t)__builtin_ctz(hits) ^ oct;
                 const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
@@ -478,7 +481,9 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 uint32_t total = nodeCount;
 #pragma unroll
                 for (int k = 0; k < 8; k++) total += (uint32_t)__builtin_popcountll(__ballot(((childHits >> k) & 1u) != 0u));
-                expand = total <= ((trav >> 8) & 0xffu) * 8u;
+                // the entries written below end before position `total`: never beyond the pool, whatever limit the caller set
+                const uint32_t limit = ((trav >> 8) & 0xffu) * 8u;
+                expand = total <= (limit < nodeCapacity - 24u ? limit : nodeCapacity - 24u);
             }
             if (expand) {
                 uint32_t waiting = childHits;
@@ -1314,6 +1319,20 @@ hipError_t launchRankTiles(const uint32_t* cost, uint32_t* order, uint32_t* clea
     if (n <= 0) return hipSuccess;
     if (n <= kExactRankTiles) hipLaunchKernelGGL(rankTilesKernel, dim3((unsigned)n), dim3(64), 0, stream, cost, order, clearNext, n);
     else hipLaunchKernelGGL(rankTilesBinnedKernel, dim3(1), dim3(1024), 0, stream, cost, order, clearNext, n);
+    return hipGetLastError();
+}
+
+// Stream-ordered rewrite of the two table entries the reference's frame loop changes between launches (Window.cpp:357-384):
+// sphere 0's geometry and plane 0's ambient colour.  The values arrive by value, so the caller's copies may change at once.
+__global__ void patchTablesKernel(F4* sphGeom0, F4 sphere0, F4* plnMat0, float kaX, float kaY, float kaZ) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        if (sphGeom0) *sphGeom0 = sphere0;
+        if (plnMat0) { plnMat0->x = kaX; plnMat0->y = kaY; plnMat0->z = kaZ; }
+    }
+}
+
+hipError_t launchPatchTables(F4* sphGeom0, F4 sphere0, F4* plnMat0, F4 plane0Mat0, hipStream_t stream) {
+    hipLaunchKernelGGL(patchTablesKernel, dim3(1), dim3(64), 0, stream, sphGeom0, sphere0, plnMat0, plane0Mat0.x, plane0Mat0.y, plane0Mat0.z);
     return hipGetLastError();
 }
 

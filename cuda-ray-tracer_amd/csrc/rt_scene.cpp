@@ -277,7 +277,12 @@ static bool isIgnoredPosition(const rt_vec3& p) { return p.x == -999.0f && p.y =
 
 // Validates a model's arrays and returns the bounds of its reachable triangles and the padding of its child boxes.
 // Child boxes are padded so that the approximate slab test of the traversal can never reject a box whose
-// triangle the exact intersection routine would accept.
+// triangle the exact intersection routine would accept.  That test forms (plane - ray origin) * (1 / d) per plane: its
+// error on the plane's axis is below 3e-7 of the distance between the ray origin and the node (five roundings of 2^-24 to
+// 2^-23 each), whatever the absolute coordinates are.  A hit that counts lies within 999 units of the ray origin, a node
+// spans at most the model, so the error stays below 3e-7 * (999 + 2 maxAbs); the pad is at least twice that.
+// (The mesh mode without a t > 0 test also accepts hits behind the ray origin at any distance: rt_api.cpp limits how far
+// the camera may be from the meshes in that mode.)
 static bool modelBounds(const rt_model& m, int modelIndex, Box& tight, float& pad, std::string& err) {
     const int64_t nTri = reachableTriangles(m.indicesCount);
     if (nTri > 0 && (!m.vertices || !m.indices)) { err = "model " + std::to_string(modelIndex) + ": null vertex or index array"; return false; }

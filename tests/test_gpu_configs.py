@@ -1,0 +1,259 @@
+"""The benchmark configurations at their full frame sizes, a moving camera, and scenes far from the world origin: the HIP
+path through the C ABI against the CPU oracle.
+
+The oracle tests every triangle of a model for every ray (as the reference does), so at full size it checks windows of the
+frame; what it cannot cover is held by size-independent properties: the plain and the instrumented kernel agree on every
+byte and on the ray count, and a frame rendered from the octrees built on the GPU (another tree shape) equals the frame
+rendered from the host-built octrees byte for byte, ids and hit distances included.
+
+Bar: primary-hit ids identical on >= 99.99 % of pixels, RGB within 1 LSB (8-bit), equal ray counts where the oracle covers
+the frame; ids and hit distances are asserted bit-equal where no libm call can interfere.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import load_package
+from parity import assert_parity, compare_frames
+
+load_package()
+from cuda_ray_tracer_amd import binding, scenes  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _gpu_frame(renderer, built, cfg, w, h):
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    rgb, ids, t, st = renderer.render_ids(w, h)
+    plain, st2 = renderer.render(w, h)
+    assert np.array_equal(plain, rgb), "instrumented and plain kernels disagree"
+    assert st.rays == st2.rays
+    return rgb, ids, t, st
+
+
+def _check_windows(oracle, built, cfg, w, h, gpu, windows, label):
+    rgb, ids, t, _ = gpu
+    for window in windows:
+        o_rgb, o_ids, o_t, _, _ = oracle.render(built.desc, built.camera, cfg, w, h, window=window, threads=16)
+        stats = compare_frames(rgb, ids, t, o_rgb, o_ids, o_t, window)
+        print(label, window, stats)
+        assert_parity(stats)
+        assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+
+
+def test_config2_full_frame_1280x720(renderer, oracle):
+    """cube + Chalice, primary + shadow rays, the whole 1280 x 720 frame against the oracle."""
+    spec, cfg, w, h = scenes.config_scene(2)
+    built = scenes.build_scene(spec)
+    rgb, ids, t, st = _gpu_frame(renderer, built, cfg, w, h)
+    o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built.desc, built.camera, cfg, w, h, threads=16)
+    stats = compare_frames(rgb, ids, t, o_rgb, o_ids, o_t)
+    print("config2 full", stats, st.rays)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+    assert (ids[..., 0] >> 24 == 4).sum() > 5000, "the meshes should be in view"
+
+
+def test_config4_room_reduced_full_frame(renderer, oracle):
+    """The nine-model room at reduced mesh detail, 480 x 270, every pixel against the oracle."""
+    spec, cfg, _, _ = scenes.config_scene(4, detail=0.3)
+    built = scenes.build_scene(spec)
+    w, h = 480, 270
+    rgb, ids, t, st = _gpu_frame(renderer, built, cfg, w, h)
+    o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built.desc, built.camera, cfg, w, h, threads=16)
+    stats = compare_frames(rgb, ids, t, o_rgb, o_ids, o_t)
+    print("config4 reduced", stats, st.rays)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+    models_seen = set(np.unique(ids[..., 0][ids[..., 0] >> 24 == 4] & 0xFFFFFF).tolist())
+    assert len(models_seen) >= 6, f"most of the room's models should be visible, saw {sorted(models_seen)}"
+
+
+def test_config4_room_full_size_3840x2160(renderer, oracle):
+    """Full-detail room at 3840 x 2160: oracle windows on the table, the chest, the bookcase and the vase, and the GPU-built
+    octrees (another tree shape) must give the same frame, ids and distances as the host-built ones."""
+    spec, cfg, w, h = scenes.config_scene(4)
+    built = scenes.build_scene(spec)
+    gpu = _gpu_frame(renderer, built, cfg, w, h)
+    windows = [(1900, 960, 1996, 1014), (2700, 850, 2796, 904), (700, 1000, 796, 1054), (1100, 700, 1196, 754)]
+    _check_windows(oracle, built, cfg, w, h, gpu, windows, "config4 4K")
+    built_dev = scenes.build_scene(spec, build_on_device=True)
+    rgb2, ids2, t2, st2 = _gpu_frame(renderer, built_dev, cfg, w, h)
+    renderer.validate_device_scene(built_dev.desc)
+    assert np.array_equal(gpu[0], rgb2) and np.array_equal(gpu[1], ids2) and np.array_equal(gpu[2].view(np.uint32), t2.view(np.uint32))
+    assert gpu[3].rays == st2.rays
+
+
+def test_config5_field_full_size_7680x4320(renderer, oracle):
+    """The field of 144 baked Chicken / WoodLog copies at 7680 x 4320, mesh detail 4 (3.3 M triangles), octrees built on the
+    GPU: oracle windows on the nearest row of models, a middle row and the farthest row."""
+    spec, cfg, w, h = scenes.config_scene(5, detail=4.0)
+    built = scenes.build_scene(spec, build_on_device=True)
+    gpu = _gpu_frame(renderer, built, cfg, w, h)
+    info = renderer.scene_info()
+    assert info.triangleCount > 3_000_000
+    windows = [(2330, 2230, 2378, 2254), (1950, 1900, 1998, 1924), (1500, 1430, 1548, 1454)]
+    _check_windows(oracle, built, cfg, w, h, gpu, windows, "config5 8K")
+    mesh_px = int((gpu[1][..., 0] >> 24 == 4).sum())
+    assert mesh_px > w * h // 25, "the field should cover a good part of the frame"
+
+
+@pytest.fixture()
+def split_renderer():
+    old = {k: os.environ.get(k) for k in ("RT_SPLIT_RATIO", "RT_SPLIT_FLOOR")}
+    os.environ["RT_SPLIT_RATIO"] = "0"
+    os.environ["RT_SPLIT_FLOOR"] = "0"
+    r = binding.Renderer(0)
+    yield r
+    r.close()
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+@pytest.mark.parametrize("config,detail", [(3, 0.2), (5, 0.35)])
+def test_camera_path_frames_back_to_back(renderer, split_renderer, oracle, config, detail):
+    """The reference's frame loop moves the camera between launches (Window.cpp:339-356).  Poses 0, 37 and 119 of the
+    benchmark's camera path are rendered back to back on one context, so that every frame is dispatched in the tile order
+    (and, on the second context, with the split blocks) chosen from the previous pose's costs; each frame must still match
+    the oracle for its own pose."""
+    spec, cfg, _, _ = scenes.config_scene(config, detail=detail)
+    built = scenes.build_scene(spec)
+    w, h = 384, 216
+    for r in (renderer, split_renderer):
+        r.upload(built.desc)
+    for k in (0, 37, 119, 37):
+        pos, yaw, pitch = scenes.camera_path_pose(spec, k)
+        cam = binding.camera_look(pos, spec.fov, yaw, pitch)
+        o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built.desc, cam, cfg, w, h, threads=16)
+        for name, r in (("plain", renderer), ("split", split_renderer)):
+            r.set_state(cam, cfg)
+            first, st1 = r.render(w, h)              # ordered by the previous pose's costs
+            rgb, ids, t, st = r.render_ids(w, h)     # ordered by this pose's costs
+            assert np.array_equal(first, rgb) and st1.rays == st.rays
+            stats = compare_frames(rgb, ids, t, o_rgb, o_ids, o_t)
+            print("path", config, k, name, stats, st.rays)
+            assert_parity(stats, st.rays, o_rays)
+            assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+
+
+def _translated(spec, off):
+    """The same scene with every object, the light and the camera moved by `off`."""
+    add = lambda p: tuple(float(np.float32(a) + np.float32(b)) for a, b in zip(p, off))
+    spec.spheres = [(add(pos),) + tuple(rest) for pos, *rest in spec.spheres]
+    spec.planes = [(add(pos),) + tuple(rest) for pos, *rest in spec.planes]
+    spec.boxes = [(add(c),) + tuple(rest) for c, *rest in spec.boxes]
+    for m in spec.models:
+        m.position = add(m.position)
+    spec.light = add(spec.light)
+    spec.cam_pos = add(spec.cam_pos)
+    return spec
+
+
+@pytest.mark.parametrize("offset", [(4000.0, -3000.0, 5000.0), (-20000.0, 9000.0, 300.0)])
+def test_scene_far_from_the_world_origin(renderer, oracle, offset):
+    """The octree child-box test is approximate and relies on padded boxes; its error must not grow with the absolute
+    coordinates.  The whole mesh scene, camera and light are moved thousands of units away: ids and hit distances must still
+    equal the oracle's bit for bit (both sides see the same translated floats)."""
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.2)
+    spec.boxes = [((60.0, 0.0, 30.0), 12.0, ((0, 1, 1), (0, 1, 1), 0.2, 0.8, 0.5, 50.0), False, 1)]
+    _translated(spec, offset)
+    built = scenes.build_scene(spec)
+    w, h = 384, 216
+    rgb, ids, t, st = _gpu_frame(renderer, built, cfg, w, h)
+    o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built.desc, built.camera, cfg, w, h, threads=16)
+    stats = compare_frames(rgb, ids, t, o_rgb, o_ids, o_t)
+    print("translated", offset, stats, st.rays)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+    assert (ids[..., 0] >> 24 == 4).sum() > 5000
+
+
+@pytest.mark.parametrize("mode", ["whole", "nobox"])
+def test_camera_far_from_meshes_near_the_origin(renderer, oracle, mode):
+    """Camera 900 units from meshes that sit at the origin, looking at them through a narrow field of view: ray origins
+    are large, box coordinates small."""
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.2)
+    spec.cam_pos = (600.0, -300.0, 640.0); spec.fov = 12.0
+    dx, dy, dz = (0.0 - spec.cam_pos[0], 0.0 - spec.cam_pos[1], 0.0 - spec.cam_pos[2])
+    spec.cam_yaw = float(np.degrees(np.arctan2(dz, dx))); spec.cam_pitch = float(np.degrees(np.arcsin(dy / np.sqrt(dx * dx + dy * dy + dz * dz))))
+    if mode == "nobox":
+        cfg.boundingBox = 0
+    built = scenes.build_scene(spec)
+    w, h = 384, 216
+    rgb, ids, t, st = _gpu_frame(renderer, built, cfg, w, h)
+    o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built.desc, built.camera, cfg, w, h, threads=16)
+    stats = compare_frames(rgb, ids, t, o_rgb, o_ids, o_t)
+    print("far camera", mode, stats, st.rays)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+    assert (ids[..., 0] >> 24 == 4).sum() > 3000
+
+
+def test_nobox_mode_rejects_a_camera_out_of_range(renderer):
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.15)
+    cfg.boundingBox = 0
+    spec.cam_pos = (0.0, -22.0, 5000.0)
+    built = scenes.build_scene(spec)
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    with pytest.raises(binding.RtError, match="within 1500 units"):
+        renderer.render(64, 64)
+    cfg.boundingBox = 1
+    renderer.set_state(built.camera, cfg)
+    renderer.render(64, 64)      # the gated modes have no such limit
+
+
+def test_dynamic_updates_do_not_disturb_frames_in_flight(renderer, oracle):
+    """Window.cpp:357-384 moves the light and its marker sphere and recolours the floor before every launch.  Two frames with
+    different values are enqueued on one stream without waiting in between; each must come out with its own values (the table
+    entries are rewritten in stream order, between the two frames)."""
+    import torch
+    from cuda_ray_tracer_amd import ctypes_types as T
+    index, cfg = scenes.preset_config("C")
+    spec = scenes.reference_scene(index)
+    scenes.apply_frame_fixups(spec, cfg)
+    built = scenes.build_scene(spec)
+    renderer.upload(built.desc)
+    w, h = 640, 360
+    states = [((-20.0, -40.0, 5.0), 3.0, (0.5, 0.4, 0.3)), ((12.0, -35.0, -30.0), 6.0, (0.1, 0.3, 0.6)), ((-20.0, -40.0, 5.0), 3.0, (0.5, 0.4, 0.3))]
+    stream = torch.cuda.Stream(device="cuda:0")
+    frames = [torch.zeros(w * h * 3, dtype=torch.uint8, device="cuda:0") for _ in states]
+    torch.cuda.synchronize()
+    for (pos, radius, ka), buf in zip(states, frames):
+        dyn = T.Dynamic()
+        dyn.setLight = 1; dyn.lightPosition = T.Vec3(*pos)
+        dyn.setSphere0 = 1; dyn.sphere0Position = T.Vec3(*pos); dyn.sphere0Radius = radius
+        dyn.setPlane0 = 1; dyn.plane0AmbientColour = T.Vec3(*ka)
+        renderer.set_state(built.camera, cfg, dyn)
+        renderer.render_device(w, h, buf.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    for (pos, radius, ka), buf in zip(states, frames):
+        spec.light = pos
+        spec.spheres[0] = (pos, radius) + tuple(spec.spheres[0][2:])
+        ppos, n, mat, typ = spec.planes[0]
+        spec.planes[0] = (ppos, n, (ka,) + tuple(mat[1:]), typ)
+        built2 = scenes.build_scene(spec)
+        o_rgb, _, _, _, _ = oracle.render(built2.desc, built2.camera, cfg, w, h, threads=16)
+        stats = compare_frames(buf.cpu().numpy().reshape(h, w, 3), None, None, o_rgb, None, None)
+        print("dynamic in flight", pos, stats)
+        assert_parity(stats)
+    assert not np.array_equal(frames[0].cpu().numpy(), frames[1].cpu().numpy())
+
+
+def test_dynamic_block_needs_a_scene(pkg):
+    from cuda_ray_tracer_amd import ctypes_types as T
+    spec, cfg, _, _ = scenes.config_scene(1)
+    built = scenes.build_scene(spec)
+    r = binding.Renderer(0)
+    try:
+        dyn = T.Dynamic(); dyn.setLight = 1; dyn.lightPosition = T.Vec3(0.0, -10.0, 0.0)
+        with pytest.raises(binding.RtError):
+            r.set_state(built.camera, cfg, dyn)
+        r.set_state(built.camera, cfg)          # without a dynamic block the state may come first
+    finally:
+        r.close()
