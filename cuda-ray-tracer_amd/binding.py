@@ -40,6 +40,7 @@ def lib():
     L.rt_render_frame.argtypes = [vp, i32, i32, vp, C.POINTER(T.FrameStats)]
     L.rt_render_frame_ids.argtypes = [vp, i32, i32, vp, vp, vp, C.POINTER(T.FrameStats)]
     L.rt_render_device.argtypes = [vp, i32, i32, vp, vp]
+    L.rt_render_device_static.argtypes = [vp, i32, i32, vp, vp]
     L.rt_tile_buffer_bytes.argtypes = [i32, i32, i32]
     L.rt_tile_buffer_bytes.restype = sz
     L.rt_render_tiles_device.argtypes = [vp, i32, i32, i32, i32, vp, sz, vp]
@@ -119,6 +120,10 @@ class Renderer:
 
     def render_device(self, width, height, d_rgb_ptr, stream=None):
         _check(lib().rt_render_device(self._ctx, width, height, C.c_void_p(d_rgb_ptr), C.c_void_p(stream or 0)))
+
+    def render_device_static(self, width, height, d_rgb_ptr, stream=None):
+        """rt_render_device with the dispatch feedback in the library's never-allocated device array."""
+        _check(lib().rt_render_device_static(self._ctx, width, height, C.c_void_p(d_rgb_ptr), C.c_void_p(stream or 0)))
 
     def render_tiles_device(self, width, height, rank, world, d_tiles_ptr, capacity, stream=None):
         _check(lib().rt_render_tiles_device(self._ctx, width, height, rank, world, C.c_void_p(d_tiles_ptr), capacity,

@@ -96,6 +96,7 @@ struct rt_ctx {
     // only decides whether a frame uses split waves at all (with split = 0 the regular waves render every block).
     volatile uint32_t* hSplitWaves = nullptr;
     uint32_t* dSplitWaves = nullptr;
+    rt::StaticScratch* staticScratch = nullptr;   // this device's record of the never-allocated scratch (rt_render_device_static)
     bool forceDeviceBuild = false;   // RT_DEVICE_BUILD=1: build every scene's octrees on the GPU
     // what rt_validate_scene_device needs besides the device arrays
     std::vector<uint32_t> mdlInfoHost;
@@ -322,6 +323,10 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     if (const char* e = std::getenv("RT_DEVICE_BUILD")) c->forceDeviceBuild = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_SPLIT")) c->split = std::atoi(e) != 0 ? 1 : 0;
     if (const char* e = std::getenv("RT_SPLIT_RATIO")) { const int v = std::atoi(e); if (v >= 0 && v <= 65536) c->splitRatio256 = v; }
+    {   // once per device, with that device current: the address of this GPU's copy of the static scratch array
+        const hipError_t se = rt::staticScratch(c->device, &c->staticScratch);
+        if (se != hipSuccess) { const int rc = failHip(se, "hipGetSymbolAddress(static scratch)"); rt_destroy(c); return rc; }
+    }
     c->residentWaves = rt::residentRenderWaves();
     if (c->residentWaves <= 0) c->split = 0;
     if (c->split) {
@@ -572,6 +577,42 @@ int rt_profile_waves(rt_ctx* ctx, int width, int height, uint64_t* clocks_out, s
     if (e == hipSuccess) e = hipMemcpy(clocks_out, d, waves * RT_WAVE_RECORD_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost);
     (void)hipFree(d);
     if (e != hipSuccess) return failHip(e, "rt_profile_waves");
+    return RT_OK;
+}
+
+int rt_render_device_static(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_stream) {
+    int rc = checkFrameArgs(ctx, width, height);
+    if (rc) return rc;
+    if (!d_rgb) return fail(RT_ERR_INVALID, "null device buffer");
+    if (!ctx->staticScratch) return fail(RT_ERR_DEVICE, "the static scratch array was not found on this device");
+    rt::FrameParams p = frameFor(ctx, width, height, 0, 1, false);
+    if (p.ownedTiles > rt::kStaticTiles)
+        return fail(RT_ERR_CAPACITY, "rt_render_device_static: frame has " + std::to_string(p.ownedTiles) + " tiles of " + std::to_string(RT_TILE) +
+                                     " x " + std::to_string(RT_TILE) + " pixels, the static scratch holds " + std::to_string(rt::kStaticTiles));
+    hipStream_t stream = static_cast<hipStream_t>(hip_stream);
+    rt::StaticScratch& sc = *ctx->staticScratch;
+    if (ctx->sphere0Dirty || ctx->plane0Dirty) {
+        RT_HIP(rt::launchPatchTables(ctx->sphere0Dirty ? const_cast<rt::F4*>(ctx->scene.sphGeom) : nullptr, ctx->sphere0Geom,
+                                     ctx->plane0Dirty ? const_cast<rt::F4*>(ctx->scene.plnMat) : nullptr, ctx->plane0Mat0, stream));
+        ctx->sphere0Dirty = ctx->plane0Dirty = false;
+    }
+    if (p.blockOrder != 2 || !ctx->costOrdering) {      // plain tile order: no scratch at all
+        RT_HIP(rt::launchRender(ctx->scene, p, static_cast<uint8_t*>(d_rgb), nullptr, nullptr, nullptr, false, stream));
+        return RT_OK;
+    }
+    // The array keeps what the last call on this GPU left in it: costs and order are only reused for the same frame geometry,
+    // and both cost buffers start from zero otherwise.
+    const long long key = planDispatch(ctx, p).key;
+    const bool haveOrder = sc.orderKey == key;
+    if (!haveOrder) RT_HIP(hipMemsetAsync(sc.words, 0, sizeof(uint32_t) * 2 * (size_t)rt::kStaticTiles, stream));
+    uint32_t* cur = sc.words + (size_t)sc.costSlot * rt::kStaticTiles;
+    uint32_t* nxt = sc.words + (size_t)(sc.costSlot ^ 1) * rt::kStaticTiles;
+    uint32_t* order = sc.words + 2 * (size_t)rt::kStaticTiles;
+    RT_HIP(rt::launchRender(ctx->scene, p, static_cast<uint8_t*>(d_rgb), nullptr, nullptr, nullptr, false, stream, nullptr,
+                            haveOrder ? order : nullptr, cur));
+    RT_HIP(rt::launchRankTiles(cur, order, nxt, p.ownedTiles, stream));
+    sc.costSlot ^= 1;
+    sc.orderKey = key;
     return RT_OK;
 }
 

@@ -31,6 +31,14 @@ unsigned launchGridBlocks(const FrameParams& P);
 // Enqueues the rewrite of sphere 0's geometry record and / or plane 0's ambient colour (null pointer = leave alone).
 hipError_t launchPatchTables(F4* sphGeom0, F4 sphere0, F4* plnMat0, F4 plane0Mat0, hipStream_t stream);
 
+// Dispatch-feedback scratch that lives in a file-scope device array instead of an allocation (rt_render_device_static):
+// words = this device's copy of the array: tile costs [0, kStaticTiles) and [kStaticTiles, 2 kStaticTiles), tile order after
+// them.  costSlot / orderKey say which cost buffer the next frame accumulates into and which frame geometry the order is for.
+constexpr int kStaticTiles = 32768;
+struct StaticScratch { uint32_t* words; int costSlot; long long orderKey; };
+// Looks the array's address up on first use per device (which must be the current device) and returns that device's record.
+hipError_t staticScratch(int device, StaticScratch** out);
+
 hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX,
                         size_t perRankBytes, hipStream_t stream);
 

@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <cstdlib>
+#include <mutex>
 
 #include "rt_device_types.h"
 #include "rt_kernels.h"
@@ -998,7 +999,12 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
         }
         // Expensive tiles first: the slowest waves of a frame run several hundred times longer than the median, so they
         // must not be the last to start.  tileOrder lists this rank's tiles by the cost measured on the previous frame.
-        if (!retire && tileOrder) localTile = tileOrder[localTile];
+        if (!retire && tileOrder) {
+            localTile = tileOrder[localTile];
+            // an order list is a permutation of the rank's tiles; should a caller ever hand over one that is not (two launches
+            // racing on a shared list), the wave gives up instead of rendering outside the frame
+            if (localTile >= (uint32_t)P.ownedTiles) retire = true;
+        }
         if (!retire && P.split && *fb.extraCount != 0u) {
             const uint32_t blk = localTile * (uint32_t)kWavesPerTile + inTile;
             if ((fb.heavyBits[blk >> 5] >> (blk & 31u)) & 1u) retire = true;      // split waves render this block
@@ -1334,6 +1340,37 @@ __global__ void patchTablesKernel(F4* sphGeom0, F4 sphere0, F4* plnMat0, float k
 hipError_t launchPatchTables(F4* sphGeom0, F4 sphere0, F4* plnMat0, F4 plane0Mat0, hipStream_t stream) {
     hipLaunchKernelGGL(patchTablesKernel, dim3(1), dim3(64), 0, stream, sphGeom0, sphere0, plnMat0, plane0Mat0.x, plane0Mat0.y, plane0Mat0.z);
     return hipGetLastError();
+}
+
+// ---------------------------------------------------------------- scratch that is never allocated
+//
+// The dispatch feedback of a frame (two tile-cost buffers used alternately, and the tile order derived from them) for callers
+// that must not allocate: kStaticTiles entries each, one copy of the array per GPU for the life of the process, shared by
+// every context on that GPU.  Host code uses the array only through the per-device address that staticScratch() looks up.
+static __device__ __align__(256) __attribute__((used)) uint32_t scratch[3 * kStaticTiles];
+
+namespace {
+constexpr int kMaxDevices = 64;
+StaticScratch g_staticScratch[kMaxDevices];
+std::mutex g_staticScratchLock;
+}
+
+hipError_t staticScratch(int device, StaticScratch** out) {
+    *out = nullptr;
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    std::lock_guard<std::mutex> guard(g_staticScratchLock);
+    StaticScratch& s = g_staticScratch[device];
+    if (!s.words) {      // first use on this device: the caller has made `device` current
+        void* p = nullptr;
+        const hipError_t e = hipGetSymbolAddress(&p, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        if (!p) return hipErrorInvalidSymbol;
+        s.words = static_cast<uint32_t*>(p);
+        s.costSlot = 0;
+        s.orderKey = -1;
+    }
+    *out = &s;
+    return hipSuccess;
 }
 
 hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX, size_t perRankBytes,

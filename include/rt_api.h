@@ -94,6 +94,20 @@ int rt_render_frame_ids(rt_ctx* ctx, int width, int height, uint8_t* rgb_out, in
  */
 int rt_render_device(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_stream);
 
+/*
+ * As rt_render_device, for callers that cannot allocate device memory and cannot rely on memory a context allocated:
+ * code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in the reference.
+ * The dispatch feedback of the frame (tile costs of the previous frame and the tile order derived from them) lives in a
+ * file-scope device array of the library instead of the context's buffers: 3 x 32768 32-bit words = 384 KiB per GPU, held
+ * by every GPU the library runs on until the process ends.  Frames of more than 32768 tiles of RT_TILE x RT_TILE pixels
+ * (7680 x 4320 has 32400) are rejected with RT_ERR_CAPACITY.  The call itself calls no hipMalloc / hipFree or allocating
+ * routine; the scene must have been uploaded and the frame state set before.  Heavy blocks are not split in this variant.
+ * Every call on a GPU shares that GPU's array, whichever context it comes through: calls that overlap on one GPU (two
+ * streams, two threads) race on it - pixels stay correct (any tile order renders the same frame), the dispatch order may
+ * not be the intended one.  The array keeps the last call's contents; a call for another frame geometry clears the costs.
+ */
+int rt_render_device_static(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_stream);
+
 /* Bytes one rank must provide to rt_render_tiles_device for a width x height frame split over `world` ranks. */
 size_t rt_tile_buffer_bytes(int width, int height, int world);
 
