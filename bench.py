@@ -22,6 +22,17 @@ HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 FP32_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak
 
 
+WORKLOADS = {
+    1: "config1: reference scene 1 (three spheres, box, floor) with the X preset, {w}x{h}",
+    2: "config2: cube + Chalice procedural meshes, {w}x{h}, primary + hard-shadow rays, mesh detail {detail}",
+    3: "config3: Crown + Vase + Crystal3 procedural meshes, {w}x{h}, hard shadows, reflections maxDepth {depth} with reflective floor, octree depth 8",
+    4: "config4: nine-model room (Table, BookCaseLargeBooks, Chest_gold, Pizza, Pug, Chalice, Vase, Crown, Book2_Open), {w}x{h}, "
+       "hard shadows, reflections maxDepth {depth} with reflective floor, mesh detail {detail}",
+    5: "config5: field of 144 baked Chicken / WoodLog copies, {w}x{h}, hard shadows, reflections maxDepth {depth} with reflective "
+       "floor, mesh detail {detail}",
+}
+
+
 def load_package():
     name = "cuda_ray_tracer_amd"
     if name in sys.modules:
@@ -34,11 +45,15 @@ def load_package():
     return mod
 
 
+INFINITY_CACHE_BYTES = 256e6   # a scene that fits is served by the L2s and the Infinity Cache: HBM is then not the roof
+
+
 def algorithmic_bytes_per_ray(st, pixels):
-    """32 B per child box slab-tested (24 B box + 8 B reference/meta), 36 B per triangle tested (three positions),
-    108 B per closest-hit attribute fetch (3 vertices x normal, Ka, Kd), 3 B of frame per pixel."""
+    """128 B per octree node visited (one record = one cache line holding the eight quantised child boxes, the child
+    reference and the leaf references), 36 B per triangle tested (three positions), 108 B per closest-hit attribute fetch
+    (3 vertices x normal, Ka, Kd), 3 B of frame per pixel."""
     rays = max(int(st.rays), 1)
-    return (32.0 * st.node_tests + 36.0 * st.tri_tests + 108.0 * st.attr_fetches + 3.0 * pixels) / rays
+    return (128.0 * st.node_visits + 36.0 * st.tri_tests + 108.0 * st.attr_fetches + 3.0 * pixels) / rays
 
 
 def algorithmic_flops_per_ray(st, info, pixels):
@@ -63,17 +78,17 @@ def cpu_baseline(scenes, built, cfg, seconds_target=15.0):
     scale = max(1.0, min(40.0, (seconds_target / probe) ** 0.5))
     w, h = int(48 * scale), int(27 * scale)
     t0 = time.perf_counter()
-    _, _, _, rays, _ = O.render(built.desc, built.camera, cfg, w, h, threads=threads, want_ids=False)
+    sample_rgb, _, _, rays, _ = O.render(built.desc, built.camera, cfg, w, h, threads=threads, want_ids=False)
     dt = time.perf_counter() - t0
     if dt < 8.0:      # the probe under-estimated: one more pass at a size that lands near 12 s
         grow = min(4.0, (12.0 / max(dt, 1e-3)) ** 0.5)
         w, h = int(w * grow), int(h * grow)
         t0 = time.perf_counter()
-        _, _, _, rays, _ = O.render(built.desc, built.camera, cfg, w, h, threads=threads, want_ids=False)
+        sample_rgb, _, _, rays, _ = O.render(built.desc, built.camera, cfg, w, h, threads=threads, want_ids=False)
         dt = time.perf_counter() - t0
     return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
             "sample": f"same scene and camera rendered at {w}x{h} ({rays} rays, {dt:.1f} s) by the CPU oracle, "
-                      f"box gate + brute-force triangle loop as the reference does, OpenMP over scanlines"}
+                      f"box gate + brute-force triangle loop as the reference does, OpenMP over scanlines"}, (w, h, sample_rgb, rays)
 
 
 def main():
@@ -94,7 +109,11 @@ def main():
                          "8x8 block and leaves most of the GPU idle)")
     ap.add_argument("--tile-slots", type=int, default=3, help="several GPUs: tile-buffer slots per rank (gathers that can be in flight or being filled)")
     ap.add_argument("--frames-per-gather", type=int, default=0, help="several GPUs: consecutive frames whose tiles one gather moves (0 = 4)")
+    ap.add_argument("--device-build", type=int, default=-1, help="1: build the octrees on the GPU, 0: on the host, -1: GPU for config 5 only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-second-leg", action="store_true",
+                    help="skip the short extra leg that repeats the measurement with the other number of frames in flight (1 <-> 2); "
+                         "profiling runs use this so that every launch of the run is of one kind")
     ap.add_argument("--out", type=str, default="", help="write the last frame as PNG (rank 0)")
     args = ap.parse_args()
     # Rank 0 prints exactly one line on stdout.  Libraries underneath write there too (RCCL prints a version banner at its
@@ -142,7 +161,8 @@ def main():
     spec, cfg, w, h = scenes.config_scene(args.config, detail=args.detail)
     if args.width and args.height:
         w, h = args.width, args.height
-    built = scenes.build_scene(spec, octree_max_depth=args.depth, octree_leaf_triangles=args.leaf)
+    device_build = args.device_build == 1 or (args.device_build < 0 and args.config == 5)
+    built = scenes.build_scene(spec, octree_max_depth=args.depth, octree_leaf_triangles=args.leaf, build_on_device=device_build)
     r = binding.Renderer(device_index)
     r.upload(built.desc)
     r.set_state(built.camera, cfg)
@@ -160,14 +180,20 @@ def main():
     if tiled and world == 1 and int(os.environ.get("RT_BENCH_EMULATE_WORLD", "0")) > 1:
         share = int(os.environ["RT_BENCH_EMULATE_WORLD"])
     in_flight = args.frames_in_flight if args.frames_in_flight > 0 else (2 if share > 1 else 1)
-    if os.environ.get("RT_BENCH_OWN_STREAM", "1" if in_flight > 1 else "0") == "1":
+    # The headline leg runs with `in_flight` frames in flight; a second, shorter leg repeats the measurement with the other of
+    # 1 and 2, so that results at every GPU count can be compared like for like (ms_per_step_by_frames_in_flight).
+    other_flight = 2 if in_flight == 1 else 1
+    second_leg = not args.no_second_leg and share == world
+    flight = [in_flight]
+    lane_count = max(in_flight, other_flight) if second_leg else in_flight
+    if os.environ.get("RT_BENCH_OWN_STREAM", "1" if lane_count > 1 else "0") == "1":
         # Several frames in flight: every lane on a stream of its own.  Work on the default stream does not overlap with work
         # on the other streams (measured: a rank's share of 1/8 of the frame, two lanes: 0.184 ms per frame with lane 0 on the
         # default stream, 0.100 ms on its own stream).
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
         stream = torch.cuda.current_stream().cuda_stream
     lanes = [(r, torch.cuda.current_stream(), frame)]
-    for _ in range(in_flight - 1):
+    for _ in range(lane_count - 1):
         extra = binding.Renderer(device_index)
         extra.upload(built.desc)
         extra.set_state(built.camera, cfg)
@@ -221,7 +247,7 @@ def main():
 
     def step(record):
         if not tiled:
-            ctx, s, buf = lanes[step_index[0] % in_flight]
+            ctx, s, buf = lanes[step_index[0] % flight[0]]
             record = record and sample_events(step_index[0])
             step_index[0] += 1
             if record:
@@ -233,7 +259,7 @@ def main():
                 kernel_events.append((e0, e1))
             return
         slot, j = (step_index[0] // batch) % slots, step_index[0] % batch
-        ctx, s, _ = lanes[step_index[0] % in_flight]
+        ctx, s, _ = lanes[step_index[0] % flight[0]]
         step_index[0] += 1
         h0 = time.perf_counter()
         if free_ev[slot] is not None:
@@ -314,18 +340,56 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / len(kernel_events) if kernel_events else elapsed * 1e3 / args.steps
+    by_flight = {str(in_flight): elapsed * 1e3 / args.steps}
+    # What the timed frames look like: the last one, as rank 0 holds it (copied now, before any other leg renders again).
+    timed_frame = frame.cpu().numpy().reshape(h, w, 3).copy() if rank == 0 else None
+    if second_leg:
+        flight[0] = other_flight
+        steps2 = max(1, min(args.steps, 200))
+        for _ in range(max(args.warmup, 2 * other_flight)):
+            step(False)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(steps2):
+            step(False)
+        fence()
+        elapsed2 = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([elapsed2], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed2 = float(tmax.item())
+        by_flight[str(other_flight)] = elapsed2 * 1e3 / steps2
+        flight[0] = in_flight
 
     if rank == 0:
+        import zlib
+        import numpy as np
         ms_per_step = elapsed * 1e3 / args.steps
         rays = int(st.rays)
-        mrays = rays / (ms_per_step * 1e-3) / 1e6
+        # one rank rehearsing its share of an n-rank run traces 1/share of the frame's rays per step
+        mrays = (rays / (share / world)) / (ms_per_step * 1e-3) / 1e6
         b_ray = algorithmic_bytes_per_ray(st, pixels)
         f_ray = algorithmic_flops_per_ray(st, info, pixels)
-        # the render kernel of this rank traces ~1/world of the frame's rays per launch
-        launch_rays = rays / world
+        # the render kernel of this rank traces ~1/share of the frame's rays per launch
+        launch_rays = rays / share
         achieved_gbs = b_ray * launch_rays / (kernel_ms * 1e-3) / 1e9
+        achieved_tflops = f_ray * launch_rays / (kernel_ms * 1e-3) / 1e12
+        # Which roof: a scene that fits the 256 MB Infinity Cache is read from HBM about once per frame whatever the rays do,
+        # and the kernel is bound by vector-instruction issue (FP32 VALU peak); a larger scene is priced against HBM.
+        # A larger scene is priced against HBM - unless its algorithmic bytes per second exceed what HBM can deliver, which
+        # proves that the rays of a frame are served from the caches (they touch the visible part of the scene again and again).
+        resident = int(info.deviceBytes) <= INFINITY_CACHE_BYTES or achieved_gbs > HBM_PEAK_GBS
+        # The timed frames are checked, not only timed: the last one must equal, byte for byte, a frame of the same scene and
+        # camera rendered outside the timed region through the blocking host entry point (one launch, one GPU).
+        check = {"frame_crc32": zlib.crc32(timed_frame.tobytes()) & 0xFFFFFFFF, "frame_nonzero_fraction": float((timed_frame != 0).mean())}
+        if share == world:
+            untimed, _ = r.render(w, h)
+            check["equals_untimed_render"] = bool(np.array_equal(untimed, timed_frame))
         traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        # HBM bytes per launch from the PMC counters of an earlier profiling run of this workload (tools/profile_all.sh)
+        tpath = os.path.join(ROOT, "profiles", f"traffic_config{args.config}.json")
+        if not os.path.exists(tpath):
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 with open(tpath) as f:
@@ -339,27 +403,43 @@ def main():
             "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"config{args.config}: Crown + Vase + Crystal3 procedural meshes, {w}x{h}, hard shadows, "
-                                   f"reflections maxDepth {cfg.maxDepth} with reflective floor, octree depth 8" if args.config == 3
-                       else f"config{args.config} at {w}x{h}",
+            "config": {"workload": WORKLOADS[args.config].format(w=w, h=h, depth=cfg.maxDepth, detail=args.detail),
                        "triangles": int(info.triangleCount), "octree_nodes": int(info.nodeCount), "rays_per_frame": rays,
-                       "rays_per_pixel": rays / pixels, "tile": binding.RT_TILE,
+                       "rays_per_pixel": rays / pixels, "tile": binding.RT_TILE, "octrees_built_on": "gpu" if device_build else "host",
                        "frames_in_flight": in_flight, "frames_per_gather": batch if tiled else None,
                        "launches_overlap": in_flight > 1,
                        "parallelism": ("1 GPU" if not tiled else f"1 GPU through the tile / gather / reassembly path (rehearsal, share of {share} ranks)") if world == 1 else f"image tiles over {world} GPUs, scene replicated, RCCL gather to rank 0"},
             "kernel_ms": kernel_ms, "host_issue_ms_per_step": enqueue * 1e3 / args.steps,
             "host_issue_parts_ms": {k: v * 1e3 / (args.steps + args.warmup) for k, v in zip(("render", "complete_previous", "gather"), host_parts)} if tiled else None,
-            "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                         "bytes_per_ray": b_ray, "node_tests_per_ray": st.node_tests / rays, "tri_tests_per_ray": st.tri_tests / rays,
-                         "attr_fetches_per_ray": st.attr_fetches / rays,
-                         "fp32_valu_frac": f_ray * launch_rays / (kernel_ms * 1e-3) / (FP32_PEAK_TFLOPS * 1e12)},
+            "ms_per_step_by_frames_in_flight": by_flight,
+            "roofline": ({"bound": "valu", "achieved": achieved_tflops, "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                          "frac": achieved_tflops / FP32_PEAK_TFLOPS} if resident else
+                         {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": achieved_gbs / HBM_PEAK_GBS}),
+            "check": check,
         }
+        out["roofline"].update({
+            "traffic": traffic, "scene_bytes": int(info.deviceBytes),
+            "why_this_bound": (("scene resident in the 256 MB Infinity Cache: HBM is read about once per frame, the kernel is bound by FP32 "
+                                "vector issue" if int(info.deviceBytes) <= INFINITY_CACHE_BYTES else
+                                "scene larger than the Infinity Cache, but the algorithmic bytes per second exceed the HBM peak: the rays are "
+                                "served from the caches, the kernel is bound by FP32 vector issue") if resident
+                               else "scene larger than the 256 MB Infinity Cache: priced against HBM bandwidth"),
+            "flops_per_ray": f_ray, "bytes_per_ray": b_ray, "algorithmic_gbs": achieved_gbs, "algorithmic_tflops": achieved_tflops,
+            "algorithmic_gbs_over_hbm_peak": achieved_gbs / HBM_PEAK_GBS,
+            "hbm_frac_measured": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+            "node_visits_per_ray": st.node_visits / rays, "node_tests_per_ray": st.node_tests / rays,
+            "tri_tests_per_ray": st.tri_tests / rays, "attr_fetches_per_ray": st.attr_fetches / rays})
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scenes, built, cfg)
+            out["cpu_baseline"], (sw, sh, sample_rgb, sample_rays) = cpu_baseline(scenes, built, cfg)
+            # the CPU leg's frame doubles as a check of the GPU path on this very scene and camera
+            g_rgb, g_st = r.render(sw, sh)
+            diff = np.abs(g_rgb.astype(np.int16) - sample_rgb.astype(np.int16)).max(axis=-1)
+            check["vs_cpu_sample"] = {"size": [sw, sh], "pixels_beyond_1_lsb": int((diff > 1).sum()), "pixels_differing": int((diff > 0).sum()),
+                                      "ray_count_equal": int(g_st.rays) == int(sample_rays)}
         if args.out:
             from PIL import Image
-            Image.fromarray(frame.cpu().numpy().reshape(h, w, 3)).save(args.out)
+            Image.fromarray(timed_frame).save(args.out)
         os.write(result_fd, (json.dumps(out) + "\n").encode())
 
     for ctx, _, _ in lanes:

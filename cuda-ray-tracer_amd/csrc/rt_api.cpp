@@ -293,6 +293,7 @@ int renderToHost(rt_ctx* ctx, int width, int height, uint8_t* rgbOut, int32_t* i
         stats->tri_tests = counters[rt::kCntTriTests];
         stats->attr_fetches = counters[rt::kCntAttrFetches];
         stats->gate_tests = counters[rt::kCntGateTests];
+        stats->node_visits = counters[rt::kCntNodeVisits];
         stats->split_waves = ctx->hSplitWaves ? *ctx->hSplitWaves : 0u;
     }
     return RT_OK;

@@ -155,6 +155,6 @@ struct SplitState {
 };
 
 // Per-launch counters (one 64-bit word each), accumulated with one atomic per wave.
-enum { kCntRays = 0, kCntNodeTests, kCntTriTests, kCntAttrFetches, kCntGateTests, kCntCount };
+enum { kCntRays = 0, kCntNodeTests, kCntTriTests, kCntAttrFetches, kCntGateTests, kCntNodeVisits, kCntCount };
 
 }  // namespace rt

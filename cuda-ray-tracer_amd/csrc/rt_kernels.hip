@@ -196,7 +196,7 @@ struct Closest {
     float u, v;
 };
 
-struct Counters { uint32_t rays, nodeTests, triTests, attrFetches, gateTests; };
+struct Counters { uint32_t rays, nodeTests, triTests, attrFetches, gateTests, nodeVisits; };
 
 // The wave's working set in LDS for the mesh traversal (tracePool); everything is indexed by lane or by pool position.
 struct WaveLds {
@@ -468,7 +468,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                     if (!enter) hmask = 0;
                 }
                 const uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
-                if (STATS) cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask);
+                if (STATS) { cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask); cnt.nodeVisits++; }
                 childBase = meta.x; childImask = nodeImask;
                 childHits = permuteOctants(hmask & nodeImask, oct);
                 pend = permuteOctants(hmask & nodeLmask, oct);
@@ -1027,7 +1027,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     const uint32_t lx = bx + (lane & 7u), ly = by + (splitWave ? sub : (lane >> 3));
     const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
 
-    Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0;
+    Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; cnt.nodeVisits = 0;
     const bool inFrame = pixelLane && x < P.width && y < P.height;
     {      // all 64 lanes, also those without a pixel: the mesh trace is a wave-wide operation
         const V3 camPos = mk(P.camPos);
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     }
     // one atomic per wave and counter
     if (counters) {
-        uint32_t vals[kCntCount] = {cnt.rays, cnt.nodeTests, cnt.triTests, cnt.attrFetches, cnt.gateTests};
+        uint32_t vals[kCntCount] = {cnt.rays, cnt.nodeTests, cnt.triTests, cnt.attrFetches, cnt.gateTests, cnt.nodeVisits};
 #pragma unroll
         for (int c = 0; c < kCntCount; c++) {
             if (!STATS && c != kCntRays) continue;
