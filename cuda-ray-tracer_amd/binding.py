@@ -50,6 +50,9 @@ def lib():
     L.rt_get_scene_info.argtypes = [vp, C.POINTER(T.SceneInfo)]
     L.rt_profile_waves.argtypes = [vp, i32, i32, vp, sz, C.POINTER(sz)]
     L.rt_validate_scene_host.argtypes = [C.POINTER(T.SceneDesc), C.POINTER(T.SceneInfo)]
+    L.rt_build_octree.argtypes = [C.POINTER(T.Model), i32, i32, C.POINTER(T.FlatOctree)]
+    L.rt_free_octree.argtypes = [C.POINTER(T.FlatOctree)]
+    L.rt_free_octree.restype = None
     L.rt_validate_scene_device.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
     L.rt_camera_look.argtypes = [C.POINTER(C.c_float), C.c_float, C.c_float, C.c_float, C.POINTER(T.Camera)]
     L.rt_bake_model.argtypes = [vp, vp, vp, vp, vp, vp, i32, vp, i32, C.POINTER(C.c_float), i32,
@@ -161,6 +164,30 @@ def validate_scene_host(scene_desc):
     info = T.SceneInfo()
     _check(lib().rt_validate_scene_host(C.byref(scene_desc), C.byref(info)))
     return info
+
+
+class FlatOctree:
+    """A model's octree as the flat node / triangle arrays the kernels read (rt_build_octree); freed with the object."""
+
+    def __init__(self, model, max_depth=0, leaf_triangles=0):
+        self.c = T.FlatOctree()
+        _check(lib().rt_build_octree(C.byref(model), max_depth, leaf_triangles, C.byref(self.c)))
+
+    def nodes(self):
+        """uint32 view [nodeCount, 32] of the node records."""
+        n = int(self.c.nodeCount)
+        return np.ctypeslib.as_array(C.cast(self.c.nodes, C.POINTER(C.c_uint32)), shape=(n, 32)) if n else np.zeros((0, 32), np.uint32)
+
+    def triangles(self):
+        """uint32 view [triangleRecords, 12] of the triangle records."""
+        n = int(self.c.triangleRecords)
+        return np.ctypeslib.as_array(C.cast(self.c.triangles, C.POINTER(C.c_uint32)), shape=(n, 12)) if n else np.zeros((0, 12), np.uint32)
+
+    def __del__(self):
+        try:
+            lib().rt_free_octree(C.byref(self.c))
+        except Exception:
+            pass
 
 
 def tile_buffer_bytes(width, height, world):

@@ -392,6 +392,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
     rt::FlatScene flat;
     std::string err;
     if (!rt::flattenScene(*scene, flat, err, onDevice)) return fail(RT_ERR_INVALID, err);
+    // octrees that came from the caller are checked against the model they claim to belong to before the GPU walks them
+    if (flat.prebuiltOctrees > 0 && !rt::validateFlatScene(*scene, flat, err)) return fail(RT_ERR_INVALID, "supplied octree: " + err);
 
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(hipDeviceSynchronize());
@@ -670,6 +672,44 @@ int rt_get_scene_info(rt_ctx* ctx, rt_scene_info* info) {
     if (!ctx->haveScene) return fail(RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
     *info = ctx->info;
     return RT_OK;
+}
+
+int rt_build_octree(const rt_model* model, int max_depth, int leaf_triangles, rt_flat_octree* out) {
+    if (!model || !out) return fail(RT_ERR_INVALID, "null argument");
+    std::memset(out, 0, sizeof *out);
+    out->maxDepth = max_depth; out->leafTriangles = leaf_triangles;
+    // a scene of this one model: its root is node 0, the other nodes follow breadth-first, triangle records start at 0
+    rt_model alone = *model;
+    alone.octree = nullptr;
+    const rt_light light = {{0.0f, 0.0f, 0.0f}, {1.0f, 1.0f, 1.0f}};
+    rt_scene_desc scene;
+    std::memset(&scene, 0, sizeof scene);
+    scene.models = &alone; scene.modelCount = 1;
+    scene.lights = &light; scene.lightCount = 1;
+    scene.octreeMaxDepth = max_depth; scene.octreeLeafTriangles = leaf_triangles;
+    rt::FlatScene flat;
+    std::string err;
+    if (!rt::flattenScene(scene, flat, err)) return fail(RT_ERR_INVALID, err);
+    if (flat.forestRoot == rt::kNoRoot) return RT_OK;
+    const size_t nodeBytes = flat.nodes.size() * sizeof(rt::F4);
+    const size_t triBytes = (size_t)flat.triangleCount * 3 * sizeof(rt::F4);     // without the spare records at the end
+    void* n = std::malloc(nodeBytes);
+    void* t = std::malloc(triBytes ? triBytes : 1);
+    if (!n || !t) { std::free(n); std::free(t); return fail(RT_ERR_INVALID, "out of host memory"); }
+    std::memcpy(n, flat.nodes.data(), nodeBytes);
+    std::memcpy(t, flat.tris.data(), triBytes);
+    out->nodes = n; out->nodeCount = flat.nodeCount;
+    out->triangles = t; out->triangleRecords = flat.triangleCount;
+    out->leafCount = (int32_t)flat.leafCount;
+    out->depth = flat.maxDepth;
+    return RT_OK;
+}
+
+void rt_free_octree(rt_flat_octree* octree) {
+    if (!octree) return;
+    std::free(const_cast<void*>(octree->nodes));
+    std::free(const_cast<void*>(octree->triangles));
+    std::memset(octree, 0, sizeof *octree);
 }
 
 int rt_validate_scene_host(const rt_scene_desc* scene, rt_scene_info* info) {

@@ -309,6 +309,15 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
     const uint32_t triBase = (uint32_t)out.triangleCount;
 
     (void)err;
+    // An octree the caller built beforehand with rt_build_octree for this very model (the host's Octree class) is spliced in
+    // below instead of building one here.
+    const rt_flat_octree* pre = (!onDevice && m.octree && m.octree->nodeCount > 0) ? m.octree : nullptr;
+    if (pre) {
+        if (!pre->nodes || !pre->triangles || pre->triangleRecords != nTri || pre->nodeCount > (int64_t)1 << 30 || pre->depth < 0 || pre->depth > kMaxModelOctreeDepth) {
+            err = "model " + std::to_string(modelIndex) + ": the supplied octree does not belong to this model";
+            return false;
+        }
+    }
     std::vector<BuildTri> btris(onDevice ? 0 : (size_t)nTri);
     for (int64_t t = 0; t < nTri && !onDevice; t++) {
         const int32_t* ix = m.indices + 3 * t;
@@ -368,7 +377,7 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
     }
 
     OctreeBuilder builder(btris, params);
-    int root = onDevice ? -1 : builder.build();
+    int root = (onDevice || pre) ? -1 : builder.build();
 
     auto emitLeaf = [&](const TreeNode& n) -> uint32_t {
         uint32_t start = (uint32_t)(out.tris.size() / 3);
@@ -431,6 +440,43 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
             }
         }
         out.maxDepth = std::max(out.maxDepth, std::max(1, builder.deepest));
+    }
+
+    if (pre) {
+        // Records of a standalone build: node 0 is the root, the others follow breadth-first with absolute child
+        // references; triangle records are numbered from 0 and tagged with model 0.  Here the root goes to the node the
+        // forest reserved, the rest to the end of the array, and every reference moves along.
+        const uint32_t base = (uint32_t)(out.nodes.size() / kNodeFloat4s);
+        const uint32_t triOffset = (uint32_t)(out.tris.size() / 3);
+        const uint32_t n = (uint32_t)pre->nodeCount;
+        out.nodes.resize(out.nodes.size() + (size_t)(n - 1) * kNodeFloat4s);
+        const uint32_t* src = static_cast<const uint32_t*>(pre->nodes);
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t w[32];
+            std::memcpy(w, src + 32 * (size_t)i, sizeof w);
+            const uint32_t imask = w[5] & 0xffu, lmask = (w[5] >> 8) & 0xffu;
+            if (imask) {
+                if (w[4] < 1u || w[4] >= n) { err = "model " + std::to_string(modelIndex) + ": supplied octree has a child reference out of range"; return false; }
+                w[4] = base + (w[4] - 1u);
+            }
+            w[6] = i == 0 ? (uint32_t)modelIndex : kNoModel;
+            for (int c = 0; c < 8; c++) {
+                if (!((lmask >> c) & 1u)) continue;
+                if (w[20 + c] >= (uint32_t)nTri) { err = "model " + std::to_string(modelIndex) + ": supplied octree has a leaf reference out of range"; return false; }
+                w[20 + c] += triOffset;
+            }
+            std::memcpy(&out.nodes[(size_t)(i == 0 ? rootIndex : base + i - 1u) * kNodeFloat4s], w, sizeof w);
+        }
+        const F4* tsrc = static_cast<const F4*>(pre->triangles);
+        for (int64_t t = 0; t < nTri; t++) {
+            F4 a = tsrc[3 * t], b = tsrc[3 * t + 1], c = tsrc[3 * t + 2];
+            b.w = bitsFloat((uint32_t)modelIndex);
+            out.tris.push_back(a); out.tris.push_back(b); out.tris.push_back(c);
+        }
+        out.leafCount += pre->leafCount;
+        out.maxDepth = std::max(out.maxDepth, std::max(1, (int)pre->depth));
+        out.prebuiltOctrees++;
+        rootRef = rootIndex;
     }
 
     F4 mat[3];

@@ -42,6 +42,7 @@ struct FlatScene {
     int forestDepth = 0;            // nesting levels above the model roots
     OctreeParams params;            // the build parameters in force
     std::vector<DeviceBuildModel> deviceModels;   // filled instead of the per-model octrees when meshes are built on the GPU
+    int prebuiltOctrees = 0;        // models whose octree the caller supplied (rt_model.octree); such a scene is validated at upload
 };
 
 // Number of triangles the reference's loops visit for a model with this many indices

@@ -55,11 +55,16 @@ class ChunkBox(C.Structure):
     _fields_ = [("min", Vec3), ("max", Vec3), ("indicesCount", c_i32), ("includedModelIndices", C.POINTER(c_i32))]
 
 
+class FlatOctree(C.Structure):
+    _fields_ = [("nodes", C.c_void_p), ("nodeCount", C.c_int64), ("triangles", C.c_void_p), ("triangleRecords", C.c_int64),
+                ("leafCount", c_i32), ("depth", c_i32), ("maxDepth", c_i32), ("leafTriangles", c_i32)]
+
+
 class Model(C.Structure):
     _fields_ = [("position", Vec3), ("size", c_i32), ("mat", Material), ("objectType", c_i32), ("debug", c_i32),
                 ("bbMin", Vec3), ("bbMax", Vec3), ("boundingBoxes", ChunkBox * 8),
                 ("vertices", C.POINTER(Vertex)), ("vertCount", c_i32),
-                ("indices", C.POINTER(c_i32)), ("indicesCount", c_i32)]
+                ("indices", C.POINTER(c_i32)), ("indicesCount", c_i32), ("octree", C.POINTER(FlatOctree))]
 
 
 class Camera(C.Structure):

@@ -71,6 +71,13 @@ Model::Model(vec3 position, int size, const char* filename, Material mat, bool d
         boundingBoxes[b].min = vec3(chunkBoxes[6 * b], chunkBoxes[6 * b + 1], chunkBoxes[6 * b + 2]);
         boundingBoxes[b].max = vec3(chunkBoxes[6 * b + 3], chunkBoxes[6 * b + 4], chunkBoxes[6 * b + 5]);
     }
+
+    // Model.cpp:119-124 (octree.init / octree.build, commented out in the reference): build the model's octree now, as the
+    // flat arrays the renderer reads.  The pointer view is left out; the arrays passed to init are only used during build.
+    octree = std::make_shared<Octree>();
+    octree->pointerView = false;
+    octree->init(toRt());
+    octree->build(octree->root);
 }
 
 void Model::buildOctree(Octree& octree, std::vector<Vertex>& soup) const {
@@ -105,5 +112,6 @@ rt_model Model::toRt() const {
     m.vertCount = vertCount;
     m.indices = indices.data();
     m.indicesCount = indicesCount;
+    m.octree = (octree && octree->built() && octree->flat().nodeCount > 0) ? &octree->flat() : nullptr;
     return m;
 }

@@ -2,6 +2,7 @@
 // space with its bounding volumes.  The baking itself is the library's rt_bake_model, which restates the body of
 // the reference constructor (integer size, mirrored Y, origin-anchored padded boxes, last triangle never copied).
 #pragma once
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -31,7 +32,13 @@ public:
 
     bool loaded = false;            // false if the OBJ file could not be read (the model is then empty)
 
-    // Pointer octree over the triangles the renderer can reach (built on demand; see Octree.h).
+    // Model.h:39 (Octree octree): built by the constructor over the baked triangles.  It holds the flat node and triangle
+    // arrays the kernels read; toRt() passes them on, so rt_upload_scene uploads this very tree.  Shared by copies of the
+    // model (the arrays are never modified after the build).
+    std::shared_ptr<Octree> octree;
+
+    // A separate octree over a triangle soup of the reachable triangles, with the OctreeNode pointer view expanded
+    // (for host code that wants to walk nodes; soupStorage must outlive the tree).
     void buildOctree(Octree& octree, std::vector<Vertex>& soupStorage) const;
 
     // View of this model for rt_upload_scene; valid while the Model is alive and unmodified.

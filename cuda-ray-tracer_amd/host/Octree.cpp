@@ -1,56 +1,105 @@
 #include "Octree.h"
 
-#include <algorithm>
-#include <limits>
-#include <vector>
+#include <cstring>
+#include <iostream>
+
+Octree::~Octree() {
+    rt_free_octree(&flat_);
+    delete root;
+}
+
+void Octree::init(Vertex* allVertices, int verticesCount) {
+    // Octree.cpp:7-9 hands the vertices to the root, which grows its box over them (OctreeNode.cpp:8-14)
+    root->add(allVertices, verticesCount);
+    const int triangles = verticesCount / 3;
+    soupIndices_.resize((size_t)triangles * 3 + 3);
+    for (int i = 0; i < triangles * 3; i++) soupIndices_[(size_t)i] = i;
+    // the renderer's loops never reach the last triangle of an index list: give them one to skip
+    for (int k = 0; k < 3; k++) soupIndices_[(size_t)triangles * 3 + (size_t)k] = 0;
+    std::memset(&source_, 0, sizeof source_);
+    source_.vertices = reinterpret_cast<const rt_vertex*>(allVertices);
+    source_.vertCount = verticesCount;
+    source_.indices = soupIndices_.data();
+    source_.indicesCount = triangles > 0 ? triangles * 3 + 3 : 0;
+    built_ = expanded_ = false;
+}
+
+void Octree::init(const rt_model& model) {
+    source_ = model;
+    source_.octree = nullptr;
+    for (int i = 0; i + 3 < model.indicesCount; i++) {
+        const rt_vertex& v = model.vertices[model.indices[i]];
+        root->boundingBox.extendBy(vec3(v.position.x, v.position.y, v.position.z));
+    }
+    built_ = expanded_ = false;
+}
+
+void Octree::build(OctreeNode* currentNode) {
+    if (currentNode != root) { std::cerr << "Octree::build: only the whole tree can be built (pass root)" << std::endl; return; }
+    rt_free_octree(&flat_);
+    built_ = expanded_ = false;
+    if (rt_build_octree(&source_, maxDepth, leafTriangles, &flat_) != RT_OK) {
+        std::cerr << "Octree::build: " << rt_last_error() << std::endl;      // the reference's policy: report and carry on
+        return;
+    }
+    built_ = true;
+    if (pointerView) expandPointerView();
+}
 
 namespace {
-struct Centre { float c[3]; };
-
-Centre triangleCentre(const Vertex* v) {
-    Centre out;
-    for (int a = 0; a < 3; a++) {
-        float lo = std::min(v[0].position[a], std::min(v[1].position[a], v[2].position[a]));
-        float hi = std::max(v[0].position[a], std::max(v[1].position[a], v[2].position[a]));
-        out.c[a] = 0.5f * lo + 0.5f * hi;
-    }
-    return out;
-}
+struct FlatNode { uint32_t w[32]; };
+inline float bitsToFloat(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 }  // namespace
 
-void Octree::subdivide(OctreeNode* node, int depth) {
-    const int triangles = node->verticesCount / 3;
-    node->isLeaf = true;
-    if (triangles <= leafTriangles || depth >= maxDepth) return;
-
-    std::vector<Centre> centres((size_t)triangles);
-    float lo[3], hi[3];
-    for (int a = 0; a < 3; a++) { lo[a] = std::numeric_limits<float>::infinity(); hi[a] = -lo[a]; }
-    for (int t = 0; t < triangles; t++) {
-        centres[(size_t)t] = triangleCentre(node->includedVertices + 3 * t);
-        for (int a = 0; a < 3; a++) { lo[a] = std::min(lo[a], centres[(size_t)t].c[a]); hi[a] = std::max(hi[a], centres[(size_t)t].c[a]); }
+void Octree::expandPointerView() {
+    if (!built_ || expanded_) return;
+    expanded_ = true;
+    delete[] root->children; root->children = nullptr;
+    root->isLeaf = true;
+    if (flat_.nodeCount == 0) return;
+    // leaf-ordered copy of the triangles' vertices, which the leaves point into
+    leafVertices_.resize((size_t)flat_.triangleRecords * 3);
+    const uint32_t* tri = static_cast<const uint32_t*>(flat_.triangles);
+    for (long long r = 0; r < flat_.triangleRecords; r++) {
+        const uint32_t id = tri[12 * r + 3] & ((1u << 27) - 1u);
+        for (int k = 0; k < 3; k++) {
+            const rt_vertex& v = source_.vertices[source_.indices[3 * (size_t)id + (size_t)k]];
+            std::memcpy(static_cast<void*>(&leafVertices_[(size_t)r * 3 + (size_t)k]), &v, sizeof(Vertex));
+        }
     }
-    float mid[3];
-    for (int a = 0; a < 3; a++) mid[a] = 0.5f * lo[a] + 0.5f * hi[a];
-    auto octant = [&](const Centre& c) { return (c.c[0] > mid[0] ? 1 : 0) | (c.c[1] > mid[1] ? 2 : 0) | (c.c[2] > mid[2] ? 4 : 0); };
+    expand(root, 0);
+}
 
-    int counts[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (const Centre& c : centres) counts[octant(c)]++;
-    if (*std::max_element(counts, counts + 8) == triangles) return;   // cannot be separated
-
+// Children of flat node `flatIndex` become the eight contiguous children of `node` (OctreeNode.h:13: children[8]): an
+// internal slot recurses, a leaf slot points at its run of triangles, an unused slot stays an empty leaf.  Boxes are the
+// decoded (outward-rounded) child boxes the traversal tests.
+void Octree::expand(OctreeNode* node, long long flatIndex) {
+    const FlatNode& n = static_cast<const FlatNode*>(flat_.nodes)[flatIndex];
+    const uint32_t imask = n.w[5] & 0xffu, lmask = (n.w[5] >> 8) & 0xffu;
     node->isLeaf = false;
     node->children = new OctreeNode[8];
-    int filled[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    Vertex* lists[8];
-    for (int k = 0; k < 8; k++) lists[k] = counts[k] ? new Vertex[(size_t)counts[k] * 3] : nullptr;
-    for (int t = 0; t < triangles; t++) {
-        int k = octant(centres[(size_t)t]);
-        for (int j = 0; j < 3; j++) lists[k][filled[k]++] = node->includedVertices[3 * t + j];
-    }
-    for (int k = 0; k < 8; k++) {
-        node->children[k].add(lists[k], counts[k] * 3);
-        node->children[k].ownsVertices = true;
-        subdivide(&node->children[k], depth + 1);
+    const uint32_t* tri = static_cast<const uint32_t*>(flat_.triangles);
+    uint32_t nextChild = n.w[4];
+    for (int c = 0; c < 8; c++) {
+        OctreeNode& ch = node->children[c];
+        if (!(((imask | lmask) >> c) & 1u)) continue;
+        for (int a = 0; a < 3; a++) {
+            const float origin = bitsToFloat(n.w[a]);
+            const float step = bitsToFloat(((n.w[3] >> (8 * a)) & 0xffu) << 23);
+            const uint32_t qlo = (n.w[8 + 4 * a + c / 4] >> (8 * (c % 4))) & 0xffu, qhi = (n.w[8 + 4 * a + 2 + c / 4] >> (8 * (c % 4))) & 0xffu;
+            ch.boundingBox.min[a] = origin + (float)qlo * step;
+            ch.boundingBox.max[a] = origin + (float)qhi * step;
+        }
+        if ((imask >> c) & 1u) {
+            expand(&ch, nextChild++);
+            for (int k = 0; k < 8; k++) ch.verticesCount += ch.children[k].verticesCount;
+        } else {
+            const uint32_t first = n.w[20 + c];
+            uint32_t last = first;
+            while (!(tri[12 * (size_t)last + 3] & 0x80000000u)) last++;
+            ch.includedVertices = &leafVertices_[(size_t)first * 3];
+            ch.verticesCount = (int)(last - first + 1u) * 3;
+        }
     }
 }
 

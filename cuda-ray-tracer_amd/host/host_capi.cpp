@@ -5,6 +5,7 @@
 #include "Headless.h"
 #include "OBJ_Loader.h"
 #include "Octree.h"
+#include "kernels.h"
 
 extern "C" {
 
@@ -15,6 +16,15 @@ void rth_key_held(void* h, char key) { static_cast<Headless*>(h)->keyHeld(key); 
 void rth_display(void* h) { static_cast<Headless*>(h)->display(); }
 const unsigned char* rth_framebuffer(void* h) { return static_cast<Headless*>(h)->rayTracer.framebuffer; }
 unsigned long long rth_last_rays(void* h) { return static_cast<Headless*>(h)->rayTracer.lastRayCount; }
+// Renders the handle's current scene through the entry point with the reference's own argument list (kernels.h:11) into
+// `out` (width * height * 3 bytes); returns its rt_status.  The per-frame fix-ups must have been applied (rth_display).
+int rth_raytrace_reference(void* h, unsigned char* out) {
+    Headless* app = static_cast<Headless*>(h);
+    setupCurand(nullptr, 0ul);
+    rayTrace(app->rayTracer.width, app->rayTracer.height, out, app->rayTracer.scene, app->rayTracer.config, nullptr);
+    return rayTraceStatus();
+}
+void rth_raytrace_shutdown() { rayTraceShutdown(); }
 void rth_add_sphere(void* h, const float* pos, float radius, const rt_material* m, int type) {
     Material mm{vec3(m->ambientColour.x, m->ambientColour.y, m->ambientColour.z), vec3(m->diffuseColour.x, m->diffuseColour.y, m->diffuseColour.z),
                 m->ambient, m->diffuse, m->specular, m->shininess};

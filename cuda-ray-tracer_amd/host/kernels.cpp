@@ -1,5 +1,72 @@
 #include "kernels.h"
 
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+
+namespace {
+
+rt_ctx* g_defaultCtx = nullptr;
+unsigned long long g_uploadedScene = 0;     // fingerprint of the scene the default context holds
+int g_lastStatus = RT_OK;
+
+void mix(unsigned long long& h, const void* data, size_t bytes) {      // FNV-1a
+    const unsigned char* p = static_cast<const unsigned char*>(data);
+    for (size_t i = 0; i < bytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
+}
+
+// Everything rt_upload_scene reads, except what travels with every frame anyway (camera, light, spheres[0] geometry,
+// planes[0] ambient colour).  Models are identified by their arrays (address and size) and their placement: the reference
+// never edits a model's vertices after construction.
+unsigned long long sceneFingerprint(rt_scene_desc desc, SceneDescStorage storage) {
+    unsigned long long h = 1469598103934665603ull;
+    if (!storage.spheres.empty()) { storage.spheres[0].position = rt_vec3{0, 0, 0}; storage.spheres[0].radius = 0; }
+    if (!storage.planes.empty()) storage.planes[0].mat.ambientColour = rt_vec3{0, 0, 0};
+    const int counts[4] = {desc.sphereCount, desc.planeCount, desc.AABBCount, desc.modelCount};
+    mix(h, counts, sizeof counts);
+    // field by field where a struct has padding
+    for (const rt_sphere& s : storage.spheres) { mix(h, &s.position, 12); mix(h, &s.radius, 4); mix(h, &s.mat, sizeof s.mat); mix(h, &s.objectType, 8); }
+    for (const rt_plane& p : storage.planes) { mix(h, &p.position, 24); mix(h, &p.mat, sizeof p.mat); mix(h, &p.objectType, 8); }
+    for (const rt_aabb& b : storage.boxes) { mix(h, &b.min, 24); mix(h, &b.mat, sizeof b.mat); mix(h, &b.objectType, 8); }
+    for (const rt_model& m : storage.models) {
+        mix(h, &m.position, 12); mix(h, &m.size, 4); mix(h, &m.mat, sizeof m.mat); mix(h, &m.objectType, 8);
+        mix(h, &m.bbMin, 24); mix(h, &m.vertices, sizeof m.vertices); mix(h, &m.vertCount, 4);
+        mix(h, &m.indices, sizeof m.indices); mix(h, &m.indicesCount, 4); mix(h, &m.octree, sizeof m.octree);
+    }
+    return h ? h : 1ull;
+}
+
+}  // namespace
+
+void rayTrace(int width, int height, GLubyte* framebuffer, const Scene& scene, const SceneConfig& config, curandState* /*randStates*/) {
+    g_lastStatus = RT_OK;
+    if (!g_defaultCtx) {
+        const char* e = std::getenv("RT_DEVICE");
+        int device = e ? std::atoi(e) : 0;
+        g_lastStatus = rt_create(1, &device, &g_defaultCtx);
+        if (g_lastStatus != RT_OK) { std::cerr << "rayTrace: " << rt_last_error() << std::endl; g_defaultCtx = nullptr; return; }
+        g_uploadedScene = 0;
+    }
+    SceneDescStorage storage;
+    rt_scene_desc desc;
+    describeScene(scene, desc, storage);
+    const unsigned long long now = sceneFingerprint(desc, storage);
+    const bool changed = now != g_uploadedScene;
+    g_lastStatus = rayTrace(g_defaultCtx, width, height, framebuffer, scene, config, changed, nullptr);
+    if (g_lastStatus != RT_OK) { std::cerr << "rayTrace: " << rt_last_error() << std::endl; return; }
+    g_uploadedScene = now;
+}
+
+int rayTraceStatus() { return g_lastStatus; }
+
+void setupCurand(curandState* /*randStates*/, unsigned long /*seed*/) {}
+
+void rayTraceShutdown() {
+    if (g_defaultCtx) rt_destroy(g_defaultCtx);
+    g_defaultCtx = nullptr;
+    g_uploadedScene = 0;
+}
+
 int rayTrace(rt_ctx* ctx, int width, int height, GLubyte* framebuffer, const Scene& scene, const SceneConfig& config,
              bool sceneChanged, rt_frame_stats* stats) {
     // the scene arrays live in HBM; they are re-flattened only when the host replaced them

@@ -171,6 +171,16 @@ const char* rt_last_error(void);
 /* ---- scene-ingest helpers (host only; no GPU needed) ---- */
 
 /*
+ * Builds the octree of one model on the host, as the flat arrays the kernels read: Octree::init + Octree::build
+ * (Octree.cpp:7-43), redefined as a spatial build (the reference's own build deals the vertex list out sequentially and
+ * is never called).  max_depth / leaf_triangles: 0 = library default.  The arrays belong to `out` until rt_free_octree.
+ * A model without reachable triangles yields nodeCount = 0.  The result may be passed back in rt_model.octree of the
+ * same model (same vertices, indices and chunk boxes).
+ */
+int rt_build_octree(const rt_model* model, int max_depth, int leaf_triangles, rt_flat_octree* out);
+void rt_free_octree(rt_flat_octree* octree);
+
+/*
  * Camera basis from position, fov, yaw and pitch in degrees: Camera::Camera + Camera::updateDirection
  * (Camera.cpp:5-20, 54-63).
  */

@@ -92,6 +92,24 @@ typedef struct rt_chunk_box {
     const int32_t* includedModelIndices;   /* indicesCount entries */
 } rt_chunk_box;
 
+/*
+ * Octree.h:6-17 + OctreeNode.h:6-20, redefined: the octree of one model as the flat arrays the kernels read instead of
+ * pointer-linked nodes.  Produced by rt_build_octree; a host that keeps the reference's Octree class hands it back
+ * through rt_model.octree and rt_upload_scene then uses it as is (after checking it) instead of building its own.
+ *   nodes      nodeCount records of 128 bytes (one cache line): origin + power-of-two steps, { childBase, internal and
+ *              leaf masks, model }, eight child boxes quantised to 8 bits per plane, eight leaf references.  Node 0 is
+ *              the root; the internal children of a node are contiguous from childBase, in slot order.
+ *   triangles  triangleRecords records of 48 bytes in leaf order: { v0, id word } { v1 - v0, model } { v2 - v0, 0 };
+ *              the id word holds the triangle's index in the model and marks the last triangle of a leaf (bit 31).
+ */
+typedef struct rt_flat_octree {
+    const void* nodes;        int64_t nodeCount;
+    const void* triangles;    int64_t triangleRecords;
+    int32_t leafCount;
+    int32_t depth;            /* deepest nesting of internal nodes */
+    int32_t maxDepth, leafTriangles;   /* the parameters it was built with (0 = library default) */
+} rt_flat_octree;
+
 /* Model.h:10-44 — a baked (world-space) mesh with its bounding volumes. */
 typedef struct rt_model {
     rt_vec3 position;
@@ -106,6 +124,7 @@ typedef struct rt_model {
     int32_t vertCount;
     const int32_t* indices;     /* indicesCount entries (Model.h:42-43) */
     int32_t indicesCount;
+    const rt_flat_octree* octree;   /* Model.h:39 (Octree octree): prebuilt by rt_build_octree for exactly this model, or NULL */
 } rt_model;
 
 /* Camera.h:6-45 — the fields the render path reads (basis is recomputed on the host). */

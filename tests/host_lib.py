@@ -26,6 +26,8 @@ def lib():
         L.rth_framebuffer.argtypes = [vp]; L.rth_framebuffer.restype = C.POINTER(C.c_ubyte)
         L.rth_last_rays.argtypes = [vp]; L.rth_last_rays.restype = C.c_ulonglong
         L.rth_add_sphere.argtypes = [vp, C.POINTER(C.c_float), C.c_float, C.POINTER(T.Material), i32]; L.rth_add_sphere.restype = None
+        L.rth_raytrace_reference.argtypes = [vp, vp]
+        L.rth_raytrace_shutdown.argtypes = []; L.rth_raytrace_shutdown.restype = None
         L.rth_describe.argtypes = [vp]; L.rth_describe.restype = C.POINTER(T.SceneDesc)
         L.rth_camera.argtypes = [vp, C.POINTER(T.Camera)]; L.rth_camera.restype = None
         L.rth_config.argtypes = [vp, C.POINTER(T.Config)]; L.rth_config.restype = None

@@ -15,9 +15,13 @@ ORACLE_SO = os.path.join(ORACLE_DIR, "liboracle.so")
 
 
 def build_oracle():
-    src = os.path.join(ORACLE_DIR, "oracle.c")
-    if not os.path.exists(ORACLE_SO) or os.path.getmtime(ORACLE_SO) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL)
+    # make knows what the library depends on (oracle.c and the C ABI's struct definitions); without a compiler at hand the
+    # prebuilt library is used as it is
+    try:
+        subprocess.check_call(["make", "-C", ORACLE_DIR], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    except (OSError, subprocess.CalledProcessError):
+        if not os.path.exists(ORACLE_SO):
+            raise
     return ORACLE_SO
 
 

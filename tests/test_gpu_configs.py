@@ -257,3 +257,26 @@ def test_dynamic_block_needs_a_scene(pkg):
         r.set_state(built.camera, cfg)          # without a dynamic block the state may come first
     finally:
         r.close()
+
+
+def test_scene_with_caller_built_octrees_renders_the_same_frame(renderer, oracle):
+    """The host's Octree class builds each model's flat octree through rt_build_octree and hands it over in rt_model.octree;
+    rt_upload_scene then uploads that tree instead of building one.  Same pixels, ids and distances as the library-built
+    scene, and parity with the oracle."""
+    import ctypes as C
+    spec, cfg, _, _ = scenes.config_scene(4, detail=0.3)
+    built = scenes.build_scene(spec)
+    w, h = 480, 270
+    base = _gpu_frame(renderer, built, cfg, w, h)
+    trees = []
+    for i in range(built.desc.modelCount):
+        trees.append(binding.FlatOctree(built.desc.models[i], max_depth=6, leaf_triangles=4))     # another shape than the default
+        built.desc.models[i].octree = C.pointer(trees[-1].c)
+    rgb, ids, t, st = _gpu_frame(renderer, built, cfg, w, h)
+    assert renderer.scene_info().nodeCount != 0
+    assert np.array_equal(rgb, base[0]) and np.array_equal(ids, base[1]) and np.array_equal(t.view(np.uint32), base[2].view(np.uint32))
+    assert st.rays == base[3].rays
+    o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built.desc, built.camera, cfg, w, h, threads=16)
+    stats = compare_frames(rgb, ids, t, o_rgb, o_ids, o_t)
+    assert_parity(stats, st.rays, o_rays)
+    assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0

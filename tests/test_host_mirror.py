@@ -138,8 +138,8 @@ def test_host_octree_holds_every_reachable_triangle(model_dir):
         stats = (C.c_int * 3)()
         L.rth_model_octree_stats(m, 8, 4, stats)
         assert stats[2] == counts[1] // 3 - 1 and stats[0] > stats[1] > 8
-        L.rth_model_octree_stats(m, 0, 4, stats)      # depth cap 0: the root stays a leaf
-        assert tuple(stats) == (1, 1, counts[1] // 3 - 1)
+        L.rth_model_octree_stats(m, 1, 1000000, stats)      # everything fits one leaf: a root node with that leaf as its only child
+        assert tuple(stats) == (9, 1, counts[1] // 3 - 1)
     finally:
         L.rth_model_free(m)
 
@@ -166,3 +166,31 @@ def test_host_mirror_renders_like_the_python_path(key, model_dir, renderer):
     renderer.set_state(built.camera, cfg)
     rgb, st = renderer.render(w, h)
     assert np.array_equal(frame, rgb) and rays == st.rays
+
+
+@pytest.mark.gpu
+def test_reference_signature_entry_point(model_dir):
+    """kernels.h:11's own argument list - rayTrace(width, height, framebuffer, scene, config, randStates) - over the default
+    context: same bytes as RayTracer::launchKernel, across a scene switch (re-upload detected from the scene itself), a moved
+    light (no re-upload) and an added sphere."""
+    L = host_lib.lib()
+    w, h = 320, 180
+    app = L.rth_create(w, h, model_dir.encode(), 0)
+    out = np.zeros((h, w, 3), np.uint8)
+    try:
+        for step in ("X", ".", "move", "add", "B"):
+            if step == "move":
+                L.rth_key_held(app, b"j")                  # moves the light and its marker sphere
+            elif step == "add":
+                mat = T.material((0, 1, 0), (0, 1, 0), 0.2, 0.8, 0.5, 50.0)
+                L.rth_add_sphere(app, (C.c_float * 3)(5.0, 0.0, 5.0), 4.0, mat, 0)
+            else:
+                L.rth_key_preset(app, step.encode())
+            L.rth_display(app)
+            frame = np.ctypeslib.as_array(L.rth_framebuffer(app), shape=(h, w, 3)).copy()
+            out[:] = 0
+            assert L.rth_raytrace_reference(app, out.ctypes.data) == 0
+            assert out.any() and np.array_equal(out, frame), step
+    finally:
+        L.rth_destroy(app)
+        L.rth_raytrace_shutdown()

@@ -1,4 +1,6 @@
 """Host-side scene flattening / octree construction, checked through rt_validate_scene_host (no GPU)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -94,3 +96,52 @@ def test_forest_over_many_models():
     spec, cfg, w, h = scenes.config_scene(5, detail=0.1)
     info = binding.validate_scene_host(scenes.build_scene(spec).desc)
     assert info.modelCount == 144
+
+
+def test_octree_built_by_the_caller_is_spliced_in_unchanged():
+    """rt_build_octree (what the host's Octree class calls) + rt_model.octree: the flattened scene must have the same size
+    and pass the same invariants as when the library builds the trees itself, for several models in one forest."""
+    spec, cfg, _, _ = scenes.config_scene(4, detail=0.25)
+    plain = scenes.build_scene(spec)
+    info0 = binding.validate_scene_host(plain.desc)
+    built = scenes.build_scene(spec)
+    trees = []
+    for i in range(built.desc.modelCount):
+        tree = binding.FlatOctree(built.desc.models[i])
+        assert tree.c.triangleRecords == built.model_meshes[i].triangle_count - 1
+        assert tree.c.nodeCount >= 1 and tree.c.leafCount >= 1
+        nodes = tree.nodes()
+        assert (nodes[0, 6] == 0) and (nodes[1:, 6] == 0xFFFFFFFF).all()      # node 0 is the model's root
+        ids = tree.triangles()[:, 3] & ((1 << 27) - 1)
+        assert sorted(ids.tolist()) == list(range(int(tree.c.triangleRecords)))   # every reachable triangle exactly once
+        built.desc.models[i].octree = C.pointer(tree.c)
+        trees.append(tree)
+    info = binding.validate_scene_host(built.desc)
+    assert (info.nodeCount, info.leafCount, info.maxDepth, info.triangleCount, info.deviceBytes) == \
+           (info0.nodeCount, info0.leafCount, info0.maxDepth, info0.triangleCount, info0.deviceBytes)
+
+
+def test_octree_of_another_model_is_rejected():
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.2)
+    built = scenes.build_scene(spec)
+    crown = binding.FlatOctree(built.desc.models[0])
+    vase = binding.FlatOctree(built.desc.models[1])
+    built.desc.models[0].octree = C.pointer(vase.c)           # wrong triangle count
+    with pytest.raises(binding.RtError, match="does not belong"):
+        binding.validate_scene_host(built.desc)
+    # right size, wrong content: the vertices move after the tree was built, so triangles leave their leaves' boxes
+    built.desc.models[0].octree = C.pointer(crown.c)
+    binding.validate_scene_host(built.desc)
+    verts = built.keep[0]["vertices"]
+    for k in range(0, built.keep[0]["vert_count"], 7):
+        verts[k].position.x += 3.0
+    with pytest.raises(binding.RtError):
+        binding.validate_scene_host(built.desc)
+
+
+def test_empty_model_has_an_empty_octree():
+    tri = [[-1, -1, -5], [1, -1, -5], [0, 1, -5]]
+    spec = simple_spec(models=[scenes.ModelSpec("test", (0, 0, 0), 1, MATTE)])
+    built = scenes.build_scene(spec, meshes={"test": mesh_from_triangles([tri])})
+    tree = binding.FlatOctree(built.desc.models[0])
+    assert tree.c.nodeCount == 0 and tree.c.triangleRecords == 0
