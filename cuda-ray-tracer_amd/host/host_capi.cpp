@@ -72,6 +72,54 @@ void rth_model_octree_stats(void* m, int maxDepth, int leafTriangles, int* out3)
     out3[0] = tree.nodeCount(); out3[1] = tree.leafCount(); out3[2] = Walk::tris(tree.root);
 }
 
+// Loader only: objl::Loader::LoadFile on `path`; the handle gives access to everything the loader produced.
+struct LoaderHolder { objl::Loader loader; bool ok = false; };
+void* rth_loader_load(const char* path) {
+    LoaderHolder* h = new LoaderHolder();
+    h->ok = h->loader.LoadFile(path);
+    return h;
+}
+void rth_loader_free(void* h) { delete static_cast<LoaderHolder*>(h); }
+// out5: LoadFile's return value, LoadedVertices, LoadedIndices, LoadedMeshes, LoadedMaterials
+void rth_loader_counts(void* h, int* out5) {
+    LoaderHolder* l = static_cast<LoaderHolder*>(h);
+    out5[0] = l->ok ? 1 : 0; out5[1] = (int)l->loader.LoadedVertices.size(); out5[2] = (int)l->loader.LoadedIndices.size();
+    out5[3] = (int)l->loader.LoadedMeshes.size(); out5[4] = (int)l->loader.LoadedMaterials.size();
+}
+static void dumpVertices(const std::vector<objl::Vertex>& v, float* out8) {
+    for (size_t i = 0; i < v.size(); i++) {
+        const float f[8] = {v[i].Position.X, v[i].Position.Y, v[i].Position.Z, v[i].Normal.X, v[i].Normal.Y, v[i].Normal.Z,
+                            v[i].TextureCoordinate.X, v[i].TextureCoordinate.Y};
+        std::memcpy(out8 + 8 * i, f, sizeof f);
+    }
+}
+// LoadedVertices as 8 floats each (position, normal, texture coordinate) and LoadedIndices
+void rth_loader_arrays(void* h, float* vertices8, unsigned int* indices) {
+    LoaderHolder* l = static_cast<LoaderHolder*>(h);
+    dumpVertices(l->loader.LoadedVertices, vertices8);
+    for (size_t i = 0; i < l->loader.LoadedIndices.size(); i++) indices[i] = l->loader.LoadedIndices[i];
+}
+// Mesh `m`: counts2 = (vertices, indices); name and material name copied into buffers of `cap` bytes; material13 = Ka, Kd,
+// Ks, Ns, Ni, d, illum; vertices8 may be null, else room for the mesh's vertices
+void rth_loader_mesh(void* h, int m, int* counts2, char* name, char* materialName, int cap, float* material13, float* vertices8) {
+    const objl::Mesh& mesh = static_cast<LoaderHolder*>(h)->loader.LoadedMeshes[(size_t)m];
+    counts2[0] = (int)mesh.Vertices.size(); counts2[1] = (int)mesh.Indices.size();
+    std::strncpy(name, mesh.MeshName.c_str(), (size_t)cap - 1); name[cap - 1] = 0;
+    const objl::Material& mt = mesh.MeshMaterial;
+    std::strncpy(materialName, mt.name.c_str(), (size_t)cap - 1); materialName[cap - 1] = 0;
+    const float f[13] = {mt.Ka.X, mt.Ka.Y, mt.Ka.Z, mt.Kd.X, mt.Kd.Y, mt.Kd.Z, mt.Ks.X, mt.Ks.Y, mt.Ks.Z, mt.Ns, mt.Ni, mt.d, (float)mt.illum};
+    std::memcpy(material13, f, sizeof f);
+    if (vertices8) dumpVertices(mesh.Vertices, vertices8);
+}
+// Material `k` of LoadedMaterials: name, map_Kd, and the 13 numbers as above
+void rth_loader_material(void* h, int k, char* name, char* mapKd, int cap, float* material13) {
+    const objl::Material& mt = static_cast<LoaderHolder*>(h)->loader.LoadedMaterials[(size_t)k];
+    std::strncpy(name, mt.name.c_str(), (size_t)cap - 1); name[cap - 1] = 0;
+    std::strncpy(mapKd, mt.map_Kd.c_str(), (size_t)cap - 1); mapKd[cap - 1] = 0;
+    const float f[13] = {mt.Ka.X, mt.Ka.Y, mt.Ka.Z, mt.Kd.X, mt.Kd.Y, mt.Kd.Z, mt.Ks.X, mt.Ks.Y, mt.Ks.Z, mt.Ns, mt.Ni, mt.d, (float)mt.illum};
+    std::memcpy(material13, f, sizeof f);
+}
+
 // Loader only: triangulation of one polygon given as n positions (3 floats each); returns the index count.
 int rth_triangulate(const float* positions, int n, unsigned int* out, int cap) {
     std::vector<objl::Vertex> corners((size_t)n);

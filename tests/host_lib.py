@@ -37,6 +37,12 @@ def lib():
         L.rth_model_view.argtypes = [vp, C.POINTER(T.Model)]; L.rth_model_view.restype = None
         L.rth_model_counts.argtypes = [vp, C.POINTER(i32)]; L.rth_model_counts.restype = None
         L.rth_model_octree_stats.argtypes = [vp, i32, i32, C.POINTER(i32)]; L.rth_model_octree_stats.restype = None
+        L.rth_loader_load.argtypes = [C.c_char_p]; L.rth_loader_load.restype = vp
+        L.rth_loader_free.argtypes = [vp]; L.rth_loader_free.restype = None
+        L.rth_loader_counts.argtypes = [vp, C.POINTER(i32)]; L.rth_loader_counts.restype = None
+        L.rth_loader_arrays.argtypes = [vp, vp, vp]; L.rth_loader_arrays.restype = None
+        L.rth_loader_mesh.argtypes = [vp, i32, C.POINTER(i32), C.c_char_p, C.c_char_p, i32, vp, vp]; L.rth_loader_mesh.restype = None
+        L.rth_loader_material.argtypes = [vp, i32, C.c_char_p, C.c_char_p, i32, vp]; L.rth_loader_material.restype = None
         L.rth_triangulate.argtypes = [C.POINTER(C.c_float), i32, C.POINTER(C.c_uint), i32]
         _lib = L
     return _lib

@@ -1,0 +1,164 @@
+"""The host's OBJ / MTL loader (cuda-ray-tracer_amd/host/OBJ_Loader.cpp, a single-pass parser written from scratch) against
+a statement-by-statement restatement of the reference's loader (oracle/obj_loader_oracle.py, citing OBJ_Loader.cpp:183-465,
+467-574, 576-741, 743-902 and the string helpers of OBJ_Loader.h:193-278).
+
+Compared bit for bit: LoadedVertices (position, normal, texture coordinate), LoadedIndices, and per mesh its name, its
+vertices, its (always empty) index list and its material; LoadedMaterials.  The loader fixes triangle order - and with it
+which triangle wins an exact tie and which one is the never-tested last triangle of a model - so this is part of the
+render path's parity.  Parity unpinned against the reference itself (it holds no loader fixtures and cannot be built here).
+"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import host_lib
+from conftest import ROOT, load_package
+
+load_package()
+from cuda_ray_tracer_amd import meshgen  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import obj_loader_oracle as ref  # noqa: E402
+
+pytestmark = pytest.mark.filterwarnings("ignore::RuntimeWarning")      # float32 overflow to inf / NaN is part of what is compared
+
+
+def _host_load(path):
+    L = host_lib.lib()
+    h = L.rth_loader_load(str(path).encode())
+    try:
+        counts = (C.c_int * 5)()
+        L.rth_loader_counts(h, counts)
+        ok, nv, ni, nm, nmat = tuple(counts)
+        verts = np.zeros((max(nv, 1), 8), np.float32)
+        idx = np.zeros(max(ni, 1), np.uint32)
+        L.rth_loader_arrays(h, verts.ctypes.data, idx.ctypes.data)
+        meshes = []
+        for m in range(nm):
+            c2 = (C.c_int * 2)()
+            name = C.create_string_buffer(256); mname = C.create_string_buffer(256)
+            mat = np.zeros(13, np.float32)
+            L.rth_loader_mesh(h, m, c2, name, mname, 256, mat.ctypes.data, None)
+            mv = np.zeros((max(c2[0], 1), 8), np.float32)
+            L.rth_loader_mesh(h, m, c2, name, mname, 256, mat.ctypes.data, mv.ctypes.data)
+            meshes.append((name.value.decode("latin-1"), c2[0], c2[1], mv[:c2[0]].copy(), mname.value.decode("latin-1"), mat.copy()))
+        materials = []
+        for k in range(nmat):
+            name = C.create_string_buffer(256); mapkd = C.create_string_buffer(256)
+            mat = np.zeros(13, np.float32)
+            L.rth_loader_material(h, k, name, mapkd, 256, mat.ctypes.data)
+            materials.append((name.value.decode("latin-1"), mapkd.value.decode("latin-1"), mat.copy()))
+        return bool(ok), verts[:nv].copy(), idx[:ni].copy(), meshes, materials
+    finally:
+        L.rth_loader_free(h)
+
+
+def _mat13(m):
+    return np.array([*m.Ka, *m.Kd, *m.Ks, m.Ns, m.Ni, m.d, np.float32(m.illum)], np.float32)
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+def _compare(path):
+    o = ref.Loader()
+    o_ok = o.load_file(str(path))
+    ok, verts, idx, meshes, materials = _host_load(path)
+    assert ok == o_ok
+    o_verts = np.array([v.floats() for v in o.LoadedVertices], np.float32).reshape(-1, 8)
+    assert verts.shape == o_verts.shape and np.array_equal(_bits(verts), _bits(o_verts)), "LoadedVertices differ"
+    assert np.array_equal(idx, np.array(o.LoadedIndices, np.uint32)), "LoadedIndices differ"
+    assert len(meshes) == len(o.LoadedMeshes)
+    for (name, nv, ni, mv, mname, mat), om in zip(meshes, o.LoadedMeshes):
+        assert name == om.MeshName
+        assert nv == len(om.Vertices) and ni == 0 and len(om.Indices) == 0          # OBJ_Loader.cpp:91-94
+        o_mv = np.array([v.floats() for v in om.Vertices], np.float32).reshape(-1, 8)
+        assert np.array_equal(_bits(mv), _bits(o_mv)), f"vertices of mesh {name} differ"
+        assert mname == om.MeshMaterial.name
+        assert np.array_equal(_bits(mat), _bits(_mat13(om.MeshMaterial))), f"material of mesh {name} differs"
+    assert len(materials) == len(o.LoadedMaterials)
+    for (name, mapkd, mat), om in zip(materials, o.LoadedMaterials):
+        assert name == om.name and mapkd == om.map_Kd
+        assert np.array_equal(_bits(mat), _bits(_mat13(om)))
+    return o
+
+
+MTL = ("# comment\nnewmtl Gold\nNs 250.000000\nKa 1.000000 1.000000 1.000000\nKd 0.800308 0.558832 0.000000\nKs 0.500000 0.500000 0.500000\n"
+       "Ke 0.0 0.0 0.0\nNi 1.450000\nd 1.000000\nillum 2\n\nnewmtl Wood\nKa 1 1 1\nKd 0.3 0.2 0.1\nKs 0 0 0\nmap_Kd Atlas.png\nKa 1 2\n"
+       "newmtl\nKd 0.5 0.5 0.5\n")
+
+CASES = {
+    "triangles_with_normals": "mtllib m.mtl\no tri\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nvn 0 0 1\nvn 0 1 0\nusemtl Gold\nf 1//1 2//1 3//1\nf 1//2 4//2 2//2\n",
+    "quad_and_pentagon_missing_normals": "o poly\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nv 2 0 0\nv 3 1 0\nv 1.5 3 0\nv -1 1 0\nf 1 2 3 4\nf 1 5 6 7 8\n",
+    "concave_hexagon": "o concave\nv 0 0 0\nv 4 0 0\nv 4 4 0\nv 2 1 0\nv 0 4 0\nv -1 2 0\nf 1 2 3 4 5 6\n",
+    "negative_and_mixed_indices": "v 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvn 0 0 1\nf -4/1/1 -3/2/1 -2/3/1\nf 1/1 2/2 3/3\nf 1//1 3//1 4\n",
+    "usemtl_splits_and_groups": "mtllib m.mtl\ng first\nv 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nv 1 1 1\nusemtl Gold\nf 1 2 3\nusemtl Wood\nf 1 3 4\nf 2 3 5\n"
+                                "g second\nusemtl none\nf 3 4 5\no third\nf 1 2 5\ng\nf 1 4 5\n",
+    "duplicate_positions_in_a_polygon": "v 0 0 0\nv 1 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4 5\nf 1 2 4 5\n",
+    "crlf_and_comments": "# made elsewhere\r\nmtllib m.mtl\r\no box\r\nv 0.5 -0.25 1e-3\r\nv 1.25 0 0\r\nv 0 2.5 0\r\nv -1 1 +0.5\r\nvn 0 0 -1\r\n"
+                         "s off\r\nusemtl Wood\r\nf 1//1 2//1 3//1 4//1\r\n",
+    "numbers": "v 0.1 0.2 0.3\nv 1e10 -1e-10 3.4028235e38\nv 0.30000001192092896 16777217 1.17549435e-38\nv 9.999999e-1 -0 .5\nf 1 2 3\nf 2 3 4\n",
+    "no_geometry": "# nothing here\nmtllib m.mtl\n",
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_hand_written_obj_text(tmp_path, name):
+    (tmp_path / "m.mtl").write_text(MTL)
+    path = tmp_path / (name + ".obj")
+    path.write_bytes(CASES[name].encode())
+    o = _compare(path)
+    if name == "quad_and_pentagon_missing_normals":
+        assert o.LoadedIndices[:6] == [0, 1, 3, 1, 2, 3]                 # the quad's two triangles, OBJ_Loader.cpp:646-684
+        assert len(o.LoadedIndices) == 6 + 9
+    if name == "usemtl_splits_and_groups":
+        assert [m.MeshName for m in o.LoadedMeshes] == ["first_2", "first", "second", "third", ""]
+        assert [m.MeshMaterial.name for m in o.LoadedMeshes] == ["Gold", "Wood", "none", "", ""]
+
+
+@pytest.mark.parametrize("model", ["cube", "Chalice", "Table", "Pizza"])
+def test_generated_models_load_identically(tmp_path, model):
+    """The synthetic stand-ins for the reference's (absent) OBJ files, with the reference's own .mtl beside them."""
+    meshes = host_lib.write_models(str(tmp_path), [model], 0.2)
+    o = _compare(tmp_path / (model + ".obj"))
+    assert len(o.LoadedIndices) == 3 * meshes[model].triangle_count
+
+
+def test_random_polygons(tmp_path):
+    """Convex polygons of 3 to 9 corners on random planes, with and without normals, separated by material changes."""
+    rng = np.random.default_rng(7)
+    lines = ["mtllib m.mtl", "o random"]
+    faces = []
+    nv = 0
+    for k in range(40):
+        n = int(rng.integers(3, 10))
+        ang = np.sort(rng.uniform(0, 2 * np.pi, n))
+        r = rng.uniform(0.5, 2.0)
+        u = rng.normal(size=3); u /= np.linalg.norm(u)
+        w = np.cross(u, rng.normal(size=3)); w /= np.linalg.norm(w)
+        c = rng.uniform(-5, 5, 3)
+        for a in ang:
+            p = c + r * (np.cos(a) * u + np.sin(a) * w)
+            lines.append("v %.6f %.6f %.6f" % tuple(p))
+        lines.append("vn %.4f %.4f %.4f" % tuple(np.cross(u, w)))
+        if k % 7 == 3:
+            lines.append("usemtl " + ("Gold" if k % 2 else "Wood"))
+        ids = range(nv + 1, nv + n + 1)
+        lines.append("f " + " ".join((f"{i}//{k + 1}" if k % 3 else f"{i}") for i in ids))
+        nv += n
+    (tmp_path / "m.mtl").write_text(MTL)
+    path = tmp_path / "random.obj"
+    path.write_text("\n".join(lines) + "\n")
+    o = _compare(path)
+    assert len(o.LoadedVertices) == nv and len(o.LoadedIndices) >= 3 * 40
+
+
+def test_string_helpers_follow_the_reference():
+    assert ref.split("1//3", "/") == ["1", "", "3"] and ref.split("1/2", "/") == ["1", "2"] and ref.split("7", "/") == ["7"]
+    assert ref.split("a  b", " ") == ["a", "", "b"]                          # OBJ_Loader.h:213-216: an empty entry per extra blank
+    assert ref.tail("  usemtl   Gold leaf \t") == "Gold leaf" and ref.tail("g") == "" and ref.first_token("\tvn 0 0 1") == "vn"
+    assert ref.first_token("") == "" and ref.tail("") == ""
