@@ -91,6 +91,11 @@ def cpu_baseline(scenes, built, cfg, seconds_target=15.0):
                       f"box gate + brute-force triangle loop as the reference does, OpenMP over scanlines"}, (w, h, sample_rgb, rays)
 
 
+def _pose(scenes, spec, k, frames):
+    pos, yaw, pitch = scenes.camera_path_pose(spec, k, frames)
+    return pos, spec.fov, yaw, pitch
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -110,6 +115,10 @@ def main():
     ap.add_argument("--tile-slots", type=int, default=3, help="several GPUs: tile-buffer slots per rank (gathers that can be in flight or being filled)")
     ap.add_argument("--frames-per-gather", type=int, default=0, help="several GPUs: consecutive frames whose tiles one gather moves (0 = 4)")
     ap.add_argument("--device-build", type=int, default=-1, help="1: build the octrees on the GPU, 0: on the host, -1: GPU for config 5 only")
+    ap.add_argument("--path-frames", type=int, default=0,
+                    help="also render this many frames of the benchmark's moving-camera path (scenes.camera_path_pose): once frame by "
+                         "frame (frame state + one launch per frame) and once through the camera-path entry point (one launch per chunk)")
+    ap.add_argument("--path-chunk", type=int, default=0, help="frames per camera-path launch (0 = 30 on one GPU, the gather batch on several)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-leg", action="store_true",
                     help="skip the short extra leg that repeats the measurement with the other number of frames in flight (1 <-> 2); "
@@ -361,6 +370,56 @@ def main():
         by_flight[str(other_flight)] = elapsed2 * 1e3 / steps2
         flight[0] = in_flight
 
+    # The moving-camera frame loop of the reference (Window.cpp:339-421), on the benchmark's fixed camera path.
+    path_result = None
+    if args.path_frames > 0:
+        n_path = args.path_frames
+        cams = [binding.camera_look(*_pose(scenes, spec, k, n_path)) for k in range(n_path)]
+        ctx0, s0, _ = lanes[0]
+        flight[0] = 1
+        if not tiled:
+            chunk = max(1, min(args.path_chunk if args.path_chunk > 0 else 30, n_path))
+            frames_buf = torch.empty(chunk * pixels * 3, dtype=torch.uint8, device=dev)
+            def loop_pass():
+                for k in range(n_path):
+                    ctx0.set_state(cams[k], cfg)
+                    ctx0.render_device(w, h, frames_buf.data_ptr() + (k % chunk) * pixels * 3, s0.cuda_stream)
+            def path_pass():
+                for k0 in range(0, n_path, chunk):
+                    ctx0.render_path_device(w, h, cams[k0:k0 + chunk], frames_buf.data_ptr(), s0.cuda_stream)
+        else:
+            chunk = batch
+            def loop_pass():
+                for k in range(n_path):
+                    ctx0.set_state(cams[k], cfg)
+                    step(False)
+            def path_pass():
+                for k0 in range(0, n_path, chunk):
+                    part = cams[k0:k0 + chunk]
+                    slot = (step_index[0] // batch) % slots
+                    if free_ev[slot] is not None:
+                        s0.wait_event(free_ev[slot])
+                    ctx0.render_path_tiles_device(w, h, rank, share, part, tiles[slot].data_ptr(), tile_bytes, s0.cuda_stream)
+                    for j in range(len(part)):
+                        rendered_ev[slot][j].record(s0)
+                    step_index[0] += batch
+                    exchange(slot, len(part))
+        timings = {}
+        for name, fn in (("frame_by_frame", loop_pass), ("one_launch_per_chunk", path_pass)):
+            fn(); fence()                       # warm-up pass: tile order under motion, allocations
+            t1 = time.perf_counter()
+            fn(); fence()
+            dt = time.perf_counter() - t1
+            if world > 1:
+                tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                dt = float(tmax.item())
+            timings[name] = dt * 1e3 / n_path
+        ctx0.set_state(built.camera, cfg)
+        flight[0] = in_flight
+        path_result = {"frames": n_path, "frames_per_launch": chunk, "ms_per_frame": timings,
+                       "note": "camera moves every frame (yaw sweep + dolly); tile order of a frame comes from the costs of the frames before it"}
+
     if rank == 0:
         import zlib
         import numpy as np
@@ -418,6 +477,8 @@ def main():
                           "frac": achieved_gbs / HBM_PEAK_GBS}),
             "check": check,
         }
+        if path_result is not None:
+            out["camera_path"] = path_result
         out["roofline"].update({
             "traffic": traffic, "scene_bytes": int(info.deviceBytes),
             "why_this_bound": (("scene resident in the 256 MB Infinity Cache: HBM is read about once per frame, the kernel is bound by FP32 "

@@ -41,6 +41,8 @@ def lib():
     L.rt_render_frame_ids.argtypes = [vp, i32, i32, vp, vp, vp, C.POINTER(T.FrameStats)]
     L.rt_render_device.argtypes = [vp, i32, i32, vp, vp]
     L.rt_render_device_static.argtypes = [vp, i32, i32, vp, vp]
+    L.rt_render_path_device.argtypes = [vp, i32, i32, i32, C.POINTER(T.Camera), vp, vp]
+    L.rt_render_path_tiles_device.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(T.Camera), vp, sz, vp]
     L.rt_tile_buffer_bytes.argtypes = [i32, i32, i32]
     L.rt_tile_buffer_bytes.restype = sz
     L.rt_render_tiles_device.argtypes = [vp, i32, i32, i32, i32, vp, sz, vp]
@@ -127,6 +129,16 @@ class Renderer:
     def render_device_static(self, width, height, d_rgb_ptr, stream=None):
         """rt_render_device with the dispatch feedback in the library's never-allocated device array."""
         _check(lib().rt_render_device_static(self._ctx, width, height, C.c_void_p(d_rgb_ptr), C.c_void_p(stream or 0)))
+
+    def render_path_device(self, width, height, cameras, d_rgb_frames_ptr, stream=None):
+        """One launch for len(cameras) frames; frame f goes to d_rgb_frames_ptr + f * 3 * width * height."""
+        arr = (T.Camera * len(cameras))(*cameras)
+        _check(lib().rt_render_path_device(self._ctx, width, height, len(cameras), arr, C.c_void_p(d_rgb_frames_ptr), C.c_void_p(stream or 0)))
+
+    def render_path_tiles_device(self, width, height, rank, world, cameras, d_tiles_ptr, frame_stride_bytes, stream=None):
+        arr = (T.Camera * len(cameras))(*cameras)
+        _check(lib().rt_render_path_tiles_device(self._ctx, width, height, rank, world, len(cameras), arr, C.c_void_p(d_tiles_ptr),
+                                                 frame_stride_bytes, C.c_void_p(stream or 0)))
 
     def render_tiles_device(self, width, height, rank, world, d_tiles_ptr, capacity, stream=None):
         _check(lib().rt_render_tiles_device(self._ctx, width, height, rank, world, C.c_void_p(d_tiles_ptr), capacity,

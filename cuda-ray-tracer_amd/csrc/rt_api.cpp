@@ -96,6 +96,9 @@ struct rt_ctx {
     // only decides whether a frame uses split waves at all (with split = 0 the regular waves render every block).
     volatile uint32_t* hSplitWaves = nullptr;
     uint32_t* dSplitWaves = nullptr;
+    float* dPathCams = nullptr;          // RT_MAX_PATH_FRAMES x 16 floats: the cameras of a camera-path launch
+    float* hPathCams = nullptr;          // pinned staging copy of the same (the asynchronous copy reads it after the call returns)
+    hipEvent_t pathCamsFree = nullptr;   // recorded after the copy out of hPathCams: the next path call waits for it before refilling
     rt::StaticScratch* staticScratch = nullptr;   // this device's record of the never-allocated scratch (rt_render_device_static)
     bool forceDeviceBuild = false;   // RT_DEVICE_BUILD=1: build every scene's octrees on the GPU
     // what rt_validate_scene_device needs besides the device arrays
@@ -358,6 +361,10 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     if (e == hipSuccess) { e = hipMalloc(&q, sizeof(uint32_t) * (rt::kMaxSplitBlocks / 32 + 8)); if (e == hipSuccess) c->dHeavyBits = static_cast<uint32_t*>(q); }
     if (e == hipSuccess) { e = hipMalloc(&q, sizeof(rt::SplitState)); if (e == hipSuccess) { c->dSplitState = static_cast<rt::SplitState*>(q); e = hipMemset(q, 0, sizeof(rt::SplitState)); } }
     if (e != hipSuccess) { rt_destroy(c); return failHip(e, "hipMalloc(tile order)"); }
+    e = hipMalloc(&q, sizeof(float) * 16 * RT_MAX_PATH_FRAMES);
+    if (e == hipSuccess) { c->dPathCams = static_cast<float*>(q); e = hipHostMalloc(&q, sizeof(float) * 16 * RT_MAX_PATH_FRAMES, hipHostMallocDefault); }
+    if (e == hipSuccess) { c->hPathCams = static_cast<float*>(q); e = hipEventCreateWithFlags(&c->pathCamsFree, hipEventDisableTiming); }
+    if (e != hipSuccess) { rt_destroy(c); return failHip(e, "camera-path buffers"); }
     e = hipEventCreate(&c->evStart);
     if (e == hipSuccess) e = hipEventCreate(&c->evStop);
     if (e != hipSuccess) { rt_destroy(c); return failHip(e, "hipEventCreate"); }
@@ -381,6 +388,9 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->dHeavyBits) (void)hipFree(ctx->dHeavyBits);
     if (ctx->dSplitState) (void)hipFree(ctx->dSplitState);
     if (ctx->hSplitWaves) (void)hipHostFree(const_cast<uint32_t*>(ctx->hSplitWaves));
+    if (ctx->dPathCams) (void)hipFree(ctx->dPathCams);
+    if (ctx->hPathCams) (void)hipHostFree(ctx->hPathCams);
+    if (ctx->pathCamsFree) (void)hipEventDestroy(ctx->pathCamsFree);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     delete ctx;
@@ -617,6 +627,74 @@ int rt_render_device_static(rt_ctx* ctx, int width, int height, void* d_rgb, voi
     sc.costSlot ^= 1;
     sc.orderKey = key;
     return RT_OK;
+}
+
+namespace {
+
+// Camera-path launch: the cameras go to the device through a pinned staging buffer (stream-ordered copy), then one launch
+// renders every frame; tile costs of all frames accumulate (maximum per tile) into the order used by the next launch.
+int renderPath(rt_ctx* ctx, int width, int height, int rank, int world, bool compact, int nFrames, const rt_camera* cams, uint8_t* out,
+               size_t frameBytes, hipStream_t stream) {
+    if (nFrames <= 0 || nFrames > RT_MAX_PATH_FRAMES) return fail(RT_ERR_INVALID, "n_frames must be 1 .. " + std::to_string(RT_MAX_PATH_FRAMES));
+    if (!cams) return fail(RT_ERR_INVALID, "null camera array");
+    rt::FrameParams p = frameFor(ctx, width, height, rank, world, compact);
+    if (p.ownedTiles <= 0) return RT_OK;
+    if ((unsigned long long)rt::launchGridBlocks(p) * (unsigned long long)nFrames > 0x7fffffffull)
+        return fail(RT_ERR_CAPACITY, "too many workgroups for one launch: render the path in shorter pieces");
+    RT_HIP(hipEventSynchronize(ctx->pathCamsFree));      // the previous path call's copy has left the staging buffer
+    for (int f = 0; f < nFrames; f++) {
+        float* d = ctx->hPathCams + 16 * (size_t)f;
+        const rt_camera& c = cams[f];
+        const float v[13] = {c.position.x, c.position.y, c.position.z, c.up.x, c.up.y, c.up.z, c.right.x, c.right.y, c.right.z,
+                             c.direction.x, c.direction.y, c.direction.z, c.fovFactor};
+        std::memcpy(d, v, sizeof v);
+        // the view vector of the specular term, as rt_update_frame_state computes it (kernels.cu:48,56)
+        const float len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        d[13] = v[0] / len; d[14] = v[1] / len; d[15] = v[2] / len;
+    }
+    RT_HIP(hipMemcpyAsync(ctx->dPathCams, ctx->hPathCams, sizeof(float) * 16 * (size_t)nFrames, hipMemcpyHostToDevice, stream));
+    RT_HIP(hipEventRecord(ctx->pathCamsFree, stream));
+    if (ctx->sphere0Dirty || ctx->plane0Dirty) {
+        RT_HIP(rt::launchPatchTables(ctx->sphere0Dirty ? const_cast<rt::F4*>(ctx->scene.sphGeom) : nullptr, ctx->sphere0Geom,
+                                     ctx->plane0Dirty ? const_cast<rt::F4*>(ctx->scene.plnMat) : nullptr, ctx->plane0Mat0, stream));
+        ctx->sphere0Dirty = ctx->plane0Dirty = false;
+    }
+    const DispatchPlan plan = planDispatch(ctx, p);
+    if (!plan.ordered) {
+        RT_HIP(rt::launchRenderPath(ctx->scene, p, out, frameBytes, nFrames, ctx->dPathCams, stream, nullptr, nullptr));
+        return RT_OK;
+    }
+    // same two-buffer scheme as launchOrdered; the block feedback for split waves is left alone (nothing is split here)
+    if (!plan.haveOrder) RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2, stream));
+    uint32_t* cur = ctx->dTileCost + (size_t)ctx->costSlot * kMaxOrderedTiles;
+    uint32_t* nxt = ctx->dTileCost + (size_t)(ctx->costSlot ^ 1) * kMaxOrderedTiles;
+    RT_HIP(rt::launchRenderPath(ctx->scene, p, out, frameBytes, nFrames, ctx->dPathCams, stream, plan.haveOrder ? ctx->dTileOrder : nullptr, cur));
+    RT_HIP(rt::launchRankTiles(cur, ctx->dTileOrder, nxt, p.ownedTiles, stream));
+    ctx->costSlot ^= 1;
+    ctx->orderKey = plan.key;
+    return RT_OK;
+}
+
+}  // namespace
+
+int rt_render_path_device(rt_ctx* ctx, int width, int height, int n_frames, const rt_camera* cams, void* d_rgb_frames, void* hip_stream) {
+    int rc = checkFrameArgs(ctx, width, height);
+    if (rc) return rc;
+    if (!d_rgb_frames) return fail(RT_ERR_INVALID, "null device buffer");
+    return renderPath(ctx, width, height, 0, 1, false, n_frames, cams, static_cast<uint8_t*>(d_rgb_frames), (size_t)width * (size_t)height * 3,
+                      static_cast<hipStream_t>(hip_stream));
+}
+
+int rt_render_path_tiles_device(rt_ctx* ctx, int width, int height, int rank, int world, int n_frames, const rt_camera* cams, void* d_tiles,
+                                size_t frame_stride_bytes, void* hip_stream) {
+    int rc = checkFrameArgs(ctx, width, height);
+    if (rc) return rc;
+    if (world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "rank/world out of range");
+    if (!d_tiles) return fail(RT_ERR_INVALID, "null device buffer");
+    if (frame_stride_bytes < rt_tile_buffer_bytes(width, height, world) || frame_stride_bytes % 16 != 0)
+        return fail(RT_ERR_INVALID, "frame stride must be a multiple of 16 and hold a tile buffer");
+    return renderPath(ctx, width, height, rank, world, true, n_frames, cams, static_cast<uint8_t*>(d_tiles), frame_stride_bytes,
+                      static_cast<hipStream_t>(hip_stream));
 }
 
 int rt_render_device(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_stream) {

@@ -15,6 +15,11 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
                         unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks = nullptr,
                         const uint32_t* tileOrder = nullptr, uint32_t* tileCost = nullptr, BlockFeedback fb = BlockFeedback{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr});
 
+// Renders `frames` frames of one geometry in one launch: frame f uses the camera dPathCams[16 f .. 16 f + 16) (device memory:
+// position, up, right, direction, fovFactor, view vector) and writes to out + f * frameBytes; everything else comes from P.
+hipError_t launchRenderPath(const DevScene& S, const FrameParams& P, uint8_t* out, size_t frameBytes, int frames, const float* dPathCams,
+                            hipStream_t stream, const uint32_t* tileOrder, uint32_t* tileCost);
+
 // Block feedback between frames (see BlockFeedback): gathers the statistics of the costs in blockCost into slot `slot` of
 // `state`, chooses the blocks the next frame renders with split waves (extraMap, heavyBits, state->used[slot]) and clears
 // blockCost.  slots = waves resident on the device at once (residentRenderWaves()).  heavyBits needs blocks / 32 + 8 words.

@@ -937,19 +937,40 @@ RT_DEV uint32_t evenBits3(uint32_t v) { return (v & 1u) | ((v >> 1) & 2u) | ((v 
 // Regular waves: one wave per 8x8 pixel block, one lane per pixel.  With P.split the grid starts with kMaxExtraWaves split
 // waves, the ones listed in fb.extraMap, each rendering one pixel row of one of the frame's heaviest blocks: eight lanes
 // bring a pixel, the other 56 only help with the mesh traversal.
-template <bool STATS>
+// Waves one frame's launch consists of (the regular waves; split waves come on top).
+__host__ __device__ inline uint32_t wavesPerFrame(const FrameParams& P) {
+    const int tilesLaunched = P.blockOrder == 2 ? ((P.ownedTiles + 7) / 8) * 8 : P.ownedTiles;
+    return (uint32_t)(tilesLaunched * kWavesPerTile);
+}
+
+// PATH: one launch renders several frames of one geometry (a camera path): workgroups [f * wavesPerFrame, (f + 1) * wavesPerFrame)
+// render frame f with the camera pathCams[f] (16 floats: position, up, right, direction, fovFactor, view vector - the layout
+// of FrameParams::camPos .. eyeDir) into out + f * pathFrameBytes.  Frames follow each other in dispatch order, so the first
+// waves of frame f + 1 fill the GPU while the slow tail of frame f drains.  Nothing is split in this mode.
+template <bool STATS, bool PATH = false>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3))) void renderKernel(DevScene sceneArg, FrameParams frameArg, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
                                                     float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
                                                     unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
-                                                    uint32_t* __restrict__ tileCost, BlockFeedback fb) {
+                                                    uint32_t* __restrict__ tileCost, BlockFeedback fb,
+                                                    const float* __restrict__ pathCams, unsigned long long pathFrameBytes) {
     // The argument structs arrive through 16-dword scalar loads, and a value that lives in such a register tuple is spilled
     // and brought back sixteen lanes at a time: every field becomes a scalar value of its own here.
     DevScene S = sceneArg; FrameParams P = frameArg;
+    uint32_t blockIndex = blockIdx.x, gridBlocks = gridDim.x;
+    if (PATH) {
+        const uint32_t perFrame = wavesPerFrame(P);
+        const uint32_t frameIndex = blockIndex / perFrame;
+        blockIndex -= frameIndex * perFrame; gridBlocks = perFrame;
+        const float* cam = pathCams + 16u * frameIndex;       // wave-uniform: scalar loads
+        for (int k = 0; k < 3; k++) { P.camPos[k] = cam[k]; P.camUp[k] = cam[3 + k]; P.camRight[k] = cam[6 + k]; P.camDir[k] = cam[9 + k]; P.eyeDir[k] = cam[13 + k]; }
+        P.fovFactor = cam[12];
+        out += (size_t)frameIndex * pathFrameBytes;
+    }
     separateScalars<19>(S); separateScalars<0>(P);
     const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
     const unsigned long long costStart = tileCost ? __builtin_amdgcn_s_memrealtime() : 0ull;    // costs are wall time in 10 ns units
-    if (fb.hint && blockIdx.x == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
-    if (fb.frameStart && blockIdx.x == 0 && threadIdx.x == 0) *fb.frameStart = costStart;
+    if (fb.hint && blockIndex == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
+    if (fb.frameStart && blockIndex == 0 && threadIdx.x == 0) *fb.frameStart = costStart;
     // Grid order with splitting: the regular waves of the heaviest unsplit tiles (the first P.leadWaves waves in tile order,
     // nearly as long as the split blocks), then the split waves, then the other regular waves; workgroups are dispatched in
     // index order.  Share of 1/2, 1/4, 1/8 of the 1080p benchmark frame, one frame in flight: 0.244 / 0.228 / 0.168 ms with
@@ -957,11 +978,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     // all of them ahead; two frames in flight: 0.151 / 0.118 / 0.090 against 0.153 / 0.111 / 0.080 ms.  (Alternating groups
     // of eight split and eight regular waves: 0.273 / 0.211 / 0.160 ms.)
     const uint32_t extraWaves = P.split ? (uint32_t)kMaxExtraWaves : 0u;      // a multiple of 8: the regular waves keep their XCDs
-    const uint32_t regularWaves = gridDim.x - extraWaves;
+    const uint32_t regularWaves = gridBlocks - extraWaves;
     // ahead of the split waves: the regular waves of the heaviest unsplit tiles (tile order), which are nearly as long
     const uint32_t lead = extraWaves ? ((uint32_t)P.leadWaves < regularWaves ? (uint32_t)P.leadWaves : regularWaves) : 0u;
-    const bool splitWave = blockIdx.x >= lead && blockIdx.x < lead + extraWaves;
-    const uint32_t waveIndex = blockIdx.x < lead ? blockIdx.x : blockIdx.x - (splitWave ? lead : extraWaves);    // among the waves of its kind
+    const bool splitWave = blockIndex >= lead && blockIndex < lead + extraWaves;
+    const uint32_t waveIndex = blockIndex < lead ? blockIndex : blockIndex - (splitWave ? lead : extraWaves);    // among the waves of its kind
     // 12416 bytes per wave: twelve waves per CU (three per SIMD) fit the 160 KB of LDS.  Measured: at 12928 bytes fewer
     // waves are resident and the frame takes 7 % longer.
     __shared__ f4_t poolRays[3 * kBlockThreads];
@@ -1161,18 +1182,26 @@ __global__ __launch_bounds__(256) void untileWideKernel(const uint8_t* __restric
 
 // ---------------------------------------------------------------- launch wrappers (host)
 
-unsigned launchGridBlocks(const FrameParams& P) {
-    const int tilesLaunched = P.blockOrder == 2 ? ((P.ownedTiles + 7) / 8) * 8 : P.ownedTiles;
-    return (unsigned)(tilesLaunched * kWavesPerTile);
-}
+unsigned launchGridBlocks(const FrameParams& P) { return wavesPerFrame(P); }
 
 hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, int32_t* ids, float* tbuf,
                         unsigned long long* counters, bool stats, hipStream_t stream, unsigned long long* waveClocks,
                         const uint32_t* tileOrder, uint32_t* tileCost, BlockFeedback fb) {
     if (P.ownedTiles <= 0) return hipSuccess;
     dim3 grid(launchGridBlocks(P) + (P.split ? (unsigned)kMaxExtraWaves : 0u)), block(kBlockThreads);
-    if (stats) hipLaunchKernelGGL((renderKernel<true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
-    else hipLaunchKernelGGL((renderKernel<false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb);
+    if (stats) hipLaunchKernelGGL((renderKernel<true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb, nullptr, 0ull);
+    else hipLaunchKernelGGL((renderKernel<false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb, nullptr, 0ull);
+    return hipGetLastError();
+}
+
+hipError_t launchRenderPath(const DevScene& S, const FrameParams& P, uint8_t* out, size_t frameBytes, int frames, const float* dPathCams,
+                            hipStream_t stream, const uint32_t* tileOrder, uint32_t* tileCost) {
+    if (P.ownedTiles <= 0 || frames <= 0) return hipSuccess;
+    const unsigned long long blocks = (unsigned long long)launchGridBlocks(P) * (unsigned long long)frames;
+    if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
+    const BlockFeedback none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipLaunchKernelGGL((renderKernel<false, true>), dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, S, P, out, (int32_t*)nullptr, (float*)nullptr,
+                       (unsigned long long*)nullptr, (unsigned long long*)nullptr, tileOrder, tileCost, none, dPathCams, (unsigned long long)frameBytes);
     return hipGetLastError();
 }
 

@@ -108,6 +108,25 @@ int rt_render_device(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_
  */
 int rt_render_device_static(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_stream);
 
+/*
+ * Renders n_frames frames of the uploaded scene along a camera path with ONE launch: frame f uses cams[f] (host array, read
+ * during the call) and everything else from the current frame state (configuration, light, sphere 0, floor colour), and is
+ * written to d_rgb_frames + f * 3 * width * height.  This is the reference's frame loop with a moving camera
+ * (Window.cpp:215-326, 338-421: camera moves, then launchKernel, every frame) folded into one enqueue: consecutive frames
+ * follow each other in dispatch order, so the first waves of a frame fill the GPU while the slow tail of the frame before it
+ * drains, and the host issues one launch per path instead of one per frame.  Byte for byte the frames rt_render_device
+ * produces one at a time.  At most RT_MAX_PATH_FRAMES frames per call.  Allocates nothing.
+ */
+#define RT_MAX_PATH_FRAMES 1024
+int rt_render_path_device(rt_ctx* ctx, int width, int height, int n_frames, const rt_camera* cams, void* d_rgb_frames, void* hip_stream);
+
+/*
+ * The same for one rank of an image-tile sharded run: frame f's tiles (layout of rt_render_tiles_device) are written to
+ * d_tiles + f * frame_stride_bytes; frame_stride_bytes >= rt_tile_buffer_bytes(width, height, world), a multiple of 16.
+ */
+int rt_render_path_tiles_device(rt_ctx* ctx, int width, int height, int rank, int world, int n_frames, const rt_camera* cams,
+                                void* d_tiles, size_t frame_stride_bytes, void* hip_stream);
+
 /* Bytes one rank must provide to rt_render_tiles_device for a width x height frame split over `world` ranks. */
 size_t rt_tile_buffer_bytes(int width, int height, int world);
 

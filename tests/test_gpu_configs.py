@@ -280,3 +280,47 @@ def test_scene_with_caller_built_octrees_renders_the_same_frame(renderer, oracle
     stats = compare_frames(rgb, ids, t, o_rgb, o_ids, o_t)
     assert_parity(stats, st.rays, o_rays)
     assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+
+
+@pytest.mark.parametrize("config,detail", [(3, 0.2), (5, 0.35)])
+def test_camera_path_in_one_launch_equals_single_frames(renderer, config, detail):
+    """rt_render_path_device / rt_render_path_tiles_device: several frames of one geometry in one launch, each with its own
+    camera.  Every frame must equal, byte for byte, the frame rt_render_device renders for that camera on its own."""
+    import torch
+    spec, cfg, _, _ = scenes.config_scene(config, detail=detail)
+    built = scenes.build_scene(spec)
+    w, h = 400, 230
+    renderer.upload(built.desc)
+    poses = [0, 17, 37, 60, 90, 119, 5]
+    cams = [binding.camera_look(*(lambda p: (p[0], spec.fov, p[1], p[2]))(scenes.camera_path_pose(spec, k))) for k in poses]
+    stream = torch.cuda.current_stream().cuda_stream
+    singles = []
+    one = torch.zeros(w * h * 3, dtype=torch.uint8, device="cuda:0")
+    for cam in cams:
+        renderer.set_state(cam, cfg)
+        renderer.render_device(w, h, one.data_ptr(), stream)
+        torch.cuda.synchronize()
+        singles.append(one.cpu().numpy().copy())
+    assert not np.array_equal(singles[0], singles[3])
+    renderer.set_state(built.camera, cfg)            # the path's cameras replace this one
+    frames = torch.zeros(len(cams) * w * h * 3, dtype=torch.uint8, device="cuda:0")
+    for _ in range(2):                               # the second launch is dispatched in the order the first one's costs give
+        frames.zero_()
+        renderer.render_path_device(w, h, cams, frames.data_ptr(), stream)
+        torch.cuda.synchronize()
+        got = frames.cpu().numpy().reshape(len(cams), -1)
+        for k in range(len(cams)):
+            assert np.array_equal(got[k], singles[k]), f"frame {k} of the path launch differs"
+    # one rank's tiles of every frame, reassembled
+    world = 3
+    per = binding.tile_buffer_bytes(w, h, world)
+    stride = per + 64
+    tiles = torch.zeros(world * len(cams) * stride, dtype=torch.uint8, device="cuda:0")
+    for rank in range(world):                        # rank r's frames at r * len(cams) * stride
+        renderer.render_path_tiles_device(w, h, rank, world, cams, tiles.data_ptr() + rank * len(cams) * stride, stride, stream)
+    for k in range(len(cams)):
+        renderer.untile_strided_device(w, h, world, tiles.data_ptr() + k * stride, len(cams) * stride, one.data_ptr(), stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(one.cpu().numpy(), singles[k]), f"frame {k} of the tiled path launch differs"
+    with pytest.raises(binding.RtError):
+        renderer.render_path_device(w, h, cams * 200, frames.data_ptr(), stream)      # more than RT_MAX_PATH_FRAMES
