@@ -1,0 +1,113 @@
+// Tile exchange over RCCL for frames sharded across the GPUs of a node (see include/rt_rccl.h).
+#include "rt_rccl.h"
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstring>
+#include <new>
+#include <string>
+
+static_assert(RT_COMM_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "identifier sizes must agree");
+
+struct rt_comm {
+    ncclComm_t comm = nullptr;
+    int rank = 0, world = 1, device = 0;
+    hipStream_t stream = nullptr;
+    uint8_t* dTiles = nullptr; size_t tilesCap = 0;
+    uint8_t* dGathered = nullptr; size_t gatheredCap = 0;     // rank 0 only
+    uint8_t* dFrame = nullptr; size_t frameCap = 0;           // rank 0 only
+};
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) { g_error = msg; return code; }
+
+#define RT_TRY_HIP(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return fail(RT_ERR_DEVICE, std::string(#call) + ": " + hipGetErrorString(e_)); } while (0)
+#define RT_TRY_NCCL(call) do { ncclResult_t r_ = (call); if (r_ != ncclSuccess) return fail(RT_ERR_DEVICE, std::string(#call) + ": " + ncclGetErrorString(r_)); } while (0)
+
+int ensure(uint8_t** buf, size_t* cap, size_t need) {
+    if (*cap >= need) return RT_OK;
+    if (*buf) { (void)hipFree(*buf); *buf = nullptr; *cap = 0; }
+    void* p = nullptr;
+    RT_TRY_HIP(hipMalloc(&p, need));
+    *buf = static_cast<uint8_t*>(p); *cap = need;
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* rt_comm_last_error(void) { return g_error.c_str(); }
+
+int rt_comm_make_id(unsigned char id[RT_COMM_ID_BYTES]) {
+    if (!id) return fail(RT_ERR_INVALID, "null identifier");
+    ncclUniqueId u;
+    RT_TRY_NCCL(ncclGetUniqueId(&u));
+    std::memcpy(id, u.internal, RT_COMM_ID_BYTES);
+    return RT_OK;
+}
+
+int rt_comm_create(const unsigned char id[RT_COMM_ID_BYTES], int rank, int world, int device, rt_comm** out) {
+    if (!id || !out) return fail(RT_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "rank/world out of range");
+    RT_TRY_HIP(hipSetDevice(device));
+    rt_comm* c = new (std::nothrow) rt_comm();
+    if (!c) return fail(RT_ERR_INVALID, "out of host memory");
+    c->rank = rank; c->world = world; c->device = device;
+    ncclUniqueId u;
+    std::memcpy(u.internal, id, RT_COMM_ID_BYTES);
+    ncclResult_t r = ncclCommInitRank(&c->comm, world, u, rank);
+    if (r != ncclSuccess) { delete c; return fail(RT_ERR_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { rt_comm_destroy(c); return fail(RT_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    *out = c;
+    return RT_OK;
+}
+
+void rt_comm_destroy(rt_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) { (void)hipStreamSynchronize(c->stream); (void)hipStreamDestroy(c->stream); }
+    if (c->dTiles) (void)hipFree(c->dTiles);
+    if (c->dGathered) (void)hipFree(c->dGathered);
+    if (c->dFrame) (void)hipFree(c->dFrame);
+    if (c->comm) (void)ncclCommDestroy(c->comm);
+    delete c;
+}
+
+int rt_gather_tiles(rt_comm* c, const void* d_tiles, size_t bytes_per_rank, void* d_gathered, void* hip_stream) {
+    if (!c || !d_tiles) return fail(RT_ERR_INVALID, "null argument");
+    if (c->rank == 0 && !d_gathered) return fail(RT_ERR_INVALID, "rank 0 needs a buffer for the gathered tiles");
+    RT_TRY_HIP(hipSetDevice(c->device));
+    RT_TRY_NCCL(ncclGather(d_tiles, d_gathered, bytes_per_rank, ncclChar, 0, c->comm, static_cast<hipStream_t>(hip_stream)));
+    return RT_OK;
+}
+
+int rt_render_frame_sharded(rt_ctx* ctx, rt_comm* c, int width, int height, uint8_t* rgb_out) {
+    if (!ctx || !c) return fail(RT_ERR_INVALID, "null argument");
+    if (c->rank == 0 && !rgb_out) return fail(RT_ERR_INVALID, "rank 0 needs an output buffer");
+    const size_t per = rt_tile_buffer_bytes(width, height, c->world);
+    if (per == 0) return fail(RT_ERR_INVALID, "bad frame size");
+    RT_TRY_HIP(hipSetDevice(c->device));
+    int rc = ensure(&c->dTiles, &c->tilesCap, per);
+    if (rc) return rc;
+    if (c->rank == 0) {
+        if ((rc = ensure(&c->dGathered, &c->gatheredCap, per * (size_t)c->world))) return rc;
+        if ((rc = ensure(&c->dFrame, &c->frameCap, (size_t)width * (size_t)height * 3))) return rc;
+    }
+    if (rt_render_tiles_device(ctx, width, height, c->rank, c->world, c->dTiles, per, c->stream) != RT_OK) return fail(RT_ERR_DEVICE, rt_last_error());
+    if ((rc = rt_gather_tiles(c, c->dTiles, per, c->dGathered, c->stream))) return rc;
+    if (c->rank == 0) {
+        if (rt_untile_device(ctx, width, height, c->world, c->dGathered, c->dFrame, c->stream) != RT_OK) return fail(RT_ERR_DEVICE, rt_last_error());
+        RT_TRY_HIP(hipMemcpyAsync(rgb_out, c->dFrame, (size_t)width * (size_t)height * 3, hipMemcpyDeviceToHost, c->stream));
+    }
+    RT_TRY_HIP(hipStreamSynchronize(c->stream));
+    return RT_OK;
+}
+
+}  // extern "C"

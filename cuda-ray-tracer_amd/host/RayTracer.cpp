@@ -211,7 +211,13 @@ void RayTracer::launchKernel() {
         return;
     }
     rt_frame_stats stats{};
-    int rc = rayTrace(ctx_, width, height, framebuffer, scene, config, sceneDirty_, &stats);
+    int rc;
+    if (renderSharded) {
+        rc = prepareFrame(ctx_, scene, config, sceneDirty_);
+        if (rc == RT_OK) rc = renderSharded(ctx_, width, height, framebuffer);
+    } else {
+        rc = rayTrace(ctx_, width, height, framebuffer, scene, config, sceneDirty_, &stats);
+    }
     if (rc != RT_OK) {
         std::cerr << "HIP Error: " << rt_last_error() << " at " << __FILE__ << ", line: " << __LINE__ << std::endl;
         return;

@@ -2,6 +2,7 @@
 // the configuration and the framebuffer, and renders through the C ABI instead of launching a kernel itself.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -89,6 +90,9 @@ public:
 
     std::string modelDirectory = "models";   // where initialiseScenes looks for <name>.obj / .mtl
     int device = 0;
+    // When set, launchKernel hands the prepared frame to this function instead of rt_render_frame: how a process that is one
+    // rank of an image-tile sharded run renders (it returns an rt_status; framebuffer is only filled on rank 0).
+    std::function<int(rt_ctx*, int, int, GLubyte*)> renderSharded;
     double lastGpuMs = 0.0;                   // device time of the last frame
     unsigned long long lastRayCount = 0;
 

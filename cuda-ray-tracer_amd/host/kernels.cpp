@@ -67,8 +67,7 @@ void rayTraceShutdown() {
     g_uploadedScene = 0;
 }
 
-int rayTrace(rt_ctx* ctx, int width, int height, GLubyte* framebuffer, const Scene& scene, const SceneConfig& config,
-             bool sceneChanged, rt_frame_stats* stats) {
+int prepareFrame(rt_ctx* ctx, const Scene& scene, const SceneConfig& config, bool sceneChanged) {
     // the scene arrays live in HBM; they are re-flattened only when the host replaced them
     if (sceneChanged) {
         SceneDescStorage storage;
@@ -84,7 +83,12 @@ int rayTrace(rt_ctx* ctx, int width, int height, GLubyte* framebuffer, const Sce
     if (!scene.lights.empty()) { dyn.setLight = 1; dyn.lightPosition = rv(scene.lights[0].position); }
     if (!scene.spheres.empty()) { dyn.setSphere0 = 1; dyn.sphere0Position = rv(scene.spheres[0].position); dyn.sphere0Radius = scene.spheres[0].radius; }
     if (!scene.planes.empty()) { dyn.setPlane0 = 1; dyn.plane0AmbientColour = rv(scene.planes[0].mat.ambientColour); }
-    int rc = rt_update_frame_state(ctx, &cam, &cfg, &dyn);
+    return rt_update_frame_state(ctx, &cam, &cfg, &dyn);
+}
+
+int rayTrace(rt_ctx* ctx, int width, int height, GLubyte* framebuffer, const Scene& scene, const SceneConfig& config,
+             bool sceneChanged, rt_frame_stats* stats) {
+    int rc = prepareFrame(ctx, scene, config, sceneChanged);
     if (rc != RT_OK) return rc;
     return rt_render_frame(ctx, width, height, framebuffer, stats);
 }

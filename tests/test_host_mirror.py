@@ -194,3 +194,21 @@ def test_reference_signature_entry_point(model_dir):
     finally:
         L.rth_destroy(app)
         L.rth_raytrace_shutdown()
+
+
+@pytest.mark.gpu
+def test_headless_driver_sharded_path_writes_the_same_frame(model_dir, tmp_path):
+    """rt_headless --sharded: the C++ host renders through rt_render_frame_sharded (this rank's tiles, RCCL gather to rank 0,
+    reassembly) - with one GPU a one-rank communicator, which still runs every step of the exchange.  Same PPM as the plain run.
+    (--gpus N forks one process per GPU and needs N GPUs; it shares all of this code but the fork.)"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(host_lib.HOST_SO), "rt_headless")
+    outs = []
+    for extra in ([], ["--sharded"]):
+        out = tmp_path / ("frame%d.ppm" % len(outs))
+        cmd = [exe, "--size", "333x201", "--preset", ".", "--frames", "3", "--models", model_dir, "--out", str(out)] + extra
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+        assert res.returncode == 0, res.stderr[-2000:]
+        assert "Average render time" in res.stdout
+        outs.append(out.read_bytes())
+    assert len(outs[0]) > 333 * 201 * 3 and outs[0] == outs[1]
