@@ -169,10 +169,22 @@ RT_DEV float wangHash(uint32_t seed) {
 
 RT_DEV uint32_t sampleSeed(int x, int y, int i) { return ((uint32_t)x * 1000u + (uint32_t)y) * 1973u + (uint32_t)i * 9277u; }
 
+// A point on the light's sphere from two hashed numbers (kernels.cu:44-46, 295-297).  The reference calls sin / cos / acos
+// on floats; every float math library rounds those a little differently, and a shadow ray whose direction moves by one
+// unit in the last place can flip at an occluder's edge.  Here (and in the CPU oracle) the three functions are evaluated in
+// double and rounded to float once, which gives the correctly rounded float result - the one value two independent
+// libraries agree on.  One out-of-line copy: the double routines are long, and soft shadows are not on the benchmark's path.
+__device__ __noinline__ f4_t lightSampleAngles(float theta, float cosPhi) {
+    const double phi = (double)(float)acos((double)cosPhi);       // float phi = acos(...)
+    f4_t r = {(float)sin(phi), (float)cos(phi), (float)sin((double)theta), (float)cos((double)theta)};
+    return r;
+}
+
 RT_DEV V3 lightSampleOffset(uint32_t seed, float radius) {
     float theta = 2 * 3.141592654f * wangHash(seed);
-    float phi = acosf(2 * wangHash(seed * 16807u) - 1);
-    return mk(radius * sinf(phi) * cosf(theta), radius * sinf(phi) * sinf(theta), radius * cosf(phi));
+    const f4_t a = lightSampleAngles(theta, 2 * wangHash(seed * 16807u) - 1);
+    const float sinPhi = a.x, cosPhi = a.y, sinTheta = a.z, cosTheta = a.w;
+    return mk(radius * sinPhi * cosTheta, radius * sinPhi * sinTheta, radius * cosPhi);
 }
 
 // ---------------------------------------------------------------- per-ray working set

@@ -438,11 +438,17 @@ static int trace_models(o_ctx* c, v3 o, v3 d, int rayType, o_hit* hit) {
 /* -------------------------------------------------------------- shading */
 
 /* kernels.cu:44-46 / 295-297 — a point on the light's sphere from two hashed numbers */
+/* The reference's sin / cos / acos on floats are evaluated in double and rounded to float once: the correctly rounded
+ * float result, which is what independent math libraries (this one, the GPU's, the reference's) can agree on. */
+static float cr_sinf(float x) { return (float)sin((double)x); }
+static float cr_cosf(float x) { return (float)cos((double)x); }
+static float cr_acosf(float x) { return (float)acos((double)x); }
+
 static v3 light_sample_offset(unsigned int seed, const rt_config* g) {
     float radius = (float)g->softShadowRadius;
     float theta = 2 * 3.141592654f * wang_hash(seed);
-    float phi = acosf(2 * wang_hash(seed * 16807u) - 1);
-    return v3_make(radius * sinf(phi) * cosf(theta), radius * sinf(phi) * sinf(theta), radius * cosf(phi));
+    float phi = cr_acosf(2 * wang_hash(seed * 16807u) - 1);
+    return v3_make(radius * cr_sinf(phi) * cr_cosf(theta), radius * cr_sinf(phi) * cr_sinf(theta), radius * cr_cosf(phi));
 }
 
 /* kernels.cu:42, 284 — (x * 1000 + y) * 1973 + i * 9277 in wrapping 32-bit arithmetic */

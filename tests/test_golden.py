@@ -46,6 +46,5 @@ def test_gpu_reproduces_golden(renderer, name):
     rgb, ids, t, st = renderer.render_ids(w, h)
     g_rgb, g_ids, g_t, g_rays = _load(name)
     stats = compare_frames(rgb, ids, t, g_rgb, g_ids, g_t)
-    soft = "soft" in name
-    assert_parity(stats, st.rays, g_rays, max_px_gt1_frac=0.005 if soft else 0.0)
+    assert_parity(stats, st.rays, g_rays)
     assert stats["id_mismatch"] == 0

@@ -154,22 +154,29 @@ def test_anti_aliasing_parity(renderer, oracle):
 
 
 def test_soft_shadows_and_area_specular(renderer, oracle):
-    """Soft-shadow sample directions come from sinf/cosf/acosf, whose last bits differ between the host and device
-    math libraries, so a sample exactly on a shadow edge can flip: 1/softShadowNum of the colour on that pixel.
-    Tolerance: at most 0.5 % of pixels beyond 1 LSB; ids (primary rays) still identical."""
+    """Soft-shadow sample directions come from sin / cos / acos of hashed numbers (kernels.cu:44-46, 295-297).  Both sides
+    evaluate them in double and round once to float - the correctly rounded value - so the sample directions are the same
+    floats and no shadow sample can flip: the 1-LSB bar holds without an allowance."""
     index, cfg = scenes.preset_config("C")
     cfg.renderSoftShadows = 1; cfg.renderHardShadows = 0; cfg.areaLightSpecularEffect = 1
     spec = scenes.reference_scene(index)
     scenes.apply_frame_fixups(spec, cfg)
     stats, st, o_rays = _run(renderer, oracle, spec, cfg, 320, 180)
     print("soft", stats, st.rays)
-    assert_parity(stats, st.rays, o_rays, max_px_gt1_frac=0.005)
+    assert_parity(stats, st.rays, o_rays)
     assert stats["id_mismatch"] == 0
     spec, cfg, _, _ = scenes.config_scene(2, detail=0.3)
     cfg.renderSoftShadows = 1; cfg.softShadowNum = 6
     stats, st, o_rays = _run(renderer, oracle, spec, cfg, 192, 108)
     print("soft mesh", stats, st.rays)
-    assert_parity(stats, st.rays, o_rays, max_px_gt1_frac=0.005)
+    assert_parity(stats, st.rays, o_rays)
+    # the seed of the random-scene campaign that once differed by 3 LSB on one pixel (a grazing soft-shadow sample)
+    from test_gpu_random_scenes import random_scene
+    spec, cfg = random_scene(101075)
+    assert cfg.renderSoftShadows == 1
+    stats, st, o_rays = _run(renderer, oracle, spec, cfg, 320, 180, build_on_device=True)      # 101075 % 3 == 2: GPU-built trees there
+    print("soft seed 101075", stats, st.rays)
+    assert_parity(stats, st.rays, o_rays)
 
 
 def test_lighting_toggles_and_cull_off(renderer, oracle):
