@@ -119,6 +119,9 @@ def main():
                     help="also render this many frames of the benchmark's moving-camera path (scenes.camera_path_pose): once frame by "
                          "frame (frame state + one launch per frame) and once through the camera-path entry point (one launch per chunk)")
     ap.add_argument("--path-chunk", type=int, default=0, help="frames per camera-path launch (0 = 30 on one GPU, the gather batch on several)")
+    ap.add_argument("--launch-per-gather", type=int, default=-1,
+                    help="several GPUs: 1 = the frames of one gather batch are rendered by ONE launch (the camera-path entry point, one "
+                         "camera per frame) instead of one launch per frame; -1 = on when frames are gathered in batches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-second-leg", action="store_true",
                     help="skip the short extra leg that repeats the measurement with the other number of frames in flight (1 <-> 2); "
@@ -247,6 +250,9 @@ def main():
                     for j in range(frames):      # rank q's buffer of the slot's j-th frame starts at q * slot_bytes + j * tile_bytes
                         r.untile_strided_device(w, h, share, gathered[slot].data_ptr() + j * tile_bytes, slot_bytes, frame.data_ptr(), xs.cuda_stream)
 
+    # Several GPUs: a rank's share of a frame is short, and issuing it costs the host as much as rendering it costs the GPU.
+    # With frames gathered in batches anyway, the whole batch goes out as one launch (rt_render_path_tiles_device).
+    batch_launch = [tiled and batch > 1 and args.launch_per_gather != 0]
     step_index = [0]
     event_period = int(os.environ.get("RT_BENCH_EVENT_PERIOD", "4"))     # every n-th launch is timed with events (0 = none)
 
@@ -268,6 +274,11 @@ def main():
                 kernel_events.append((e0, e1))
             return
         slot, j = (step_index[0] // batch) % slots, step_index[0] % batch
+        if batch_launch[0]:
+            step_index[0] += 1
+            if j == batch - 1:
+                issue_batch(slot, batch, record)
+            return
         ctx, s, _ = lanes[step_index[0] % flight[0]]
         step_index[0] += 1
         h0 = time.perf_counter()
@@ -285,6 +296,26 @@ def main():
         host_parts[0] += time.perf_counter() - h0
         if j == batch - 1:
             exchange(slot, batch)
+
+    def issue_batch(slot, frames, record):
+        """One launch for `frames` consecutive frames of this rank's tiles into `slot`, then the slot's gather."""
+        batch_no = (step_index[0] - 1) // batch
+        ctx, s, _ = lanes[batch_no % flight[0]]
+        h0 = time.perf_counter()
+        if free_ev[slot] is not None:
+            s.wait_event(free_ev[slot])
+        record = record and sample_events(batch_no)
+        if record:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(s)
+        ctx.render_path_tiles_device(w, h, rank, share, [built.camera] * frames, tiles[slot].data_ptr(), tile_bytes, s.cuda_stream)
+        if record:
+            e1.record(s)
+            kernel_events.append((e0, e1, frames))
+        for j in range(frames):
+            rendered_ev[slot][j].record(s)
+        host_parts[0] += time.perf_counter() - h0
+        exchange(slot, frames)
 
     def exchange(slot, frames):
         h1 = time.perf_counter()
@@ -307,7 +338,10 @@ def main():
     def fence():
         if tiled:
             if step_index[0] % batch != 0:       # a slot that is only partly filled: gather it as it is
-                exchange((step_index[0] // batch) % slots, step_index[0] % batch)
+                if batch_launch[0]:
+                    issue_batch((step_index[0] // batch) % slots, step_index[0] % batch, False)
+                else:
+                    exchange((step_index[0] // batch) % slots, step_index[0] % batch)
                 step_index[0] += batch - step_index[0] % batch
             finish_pending()
             if os.environ.get("RT_BENCH_DEBUG_HANG"):
@@ -348,7 +382,9 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    kernel_ms = sum(a.elapsed_time(b) for a, b in kernel_events) / len(kernel_events) if kernel_events else elapsed * 1e3 / args.steps
+    # per frame: a launch that renders several frames counts with that many
+    kernel_ms = (sum(ev[0].elapsed_time(ev[1]) for ev in kernel_events) / sum(ev[2] if len(ev) > 2 else 1 for ev in kernel_events)
+                 if kernel_events else elapsed * 1e3 / args.steps)
     by_flight = {str(in_flight): elapsed * 1e3 / args.steps}
     # What the timed frames look like: the last one, as rank 0 holds it (copied now, before any other leg renders again).
     timed_frame = frame.cpu().numpy().reshape(h, w, 3).copy() if rank == 0 else None
@@ -390,9 +426,13 @@ def main():
         else:
             chunk = batch
             def loop_pass():
+                keep = batch_launch[0]
+                batch_launch[0] = False              # one frame state and one launch per frame
                 for k in range(n_path):
                     ctx0.set_state(cams[k], cfg)
                     step(False)
+                fence()
+                batch_launch[0] = keep
             def path_pass():
                 for k0 in range(0, n_path, chunk):
                     part = cams[k0:k0 + chunk]
@@ -466,6 +506,7 @@ def main():
                        "triangles": int(info.triangleCount), "octree_nodes": int(info.nodeCount), "rays_per_frame": rays,
                        "rays_per_pixel": rays / pixels, "tile": binding.RT_TILE, "octrees_built_on": "gpu" if device_build else "host",
                        "frames_in_flight": in_flight, "frames_per_gather": batch if tiled else None,
+                       "frames_per_launch": (batch if batch_launch[0] else 1) if tiled else 1,
                        "launches_overlap": in_flight > 1,
                        "parallelism": ("1 GPU" if not tiled else f"1 GPU through the tile / gather / reassembly path (rehearsal, share of {share} ranks)") if world == 1 else f"image tiles over {world} GPUs, scene replicated, RCCL gather to rank 0"},
             "kernel_ms": kernel_ms, "host_issue_ms_per_step": enqueue * 1e3 / args.steps,

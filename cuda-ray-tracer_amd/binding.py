@@ -37,6 +37,7 @@ def lib():
     L.rt_destroy.restype = None
     L.rt_upload_scene.argtypes = [vp, C.POINTER(T.SceneDesc)]
     L.rt_update_frame_state.argtypes = [vp, C.POINTER(T.Camera), C.POINTER(T.Config), C.POINTER(T.Dynamic)]
+    L.rt_set_strict_octree_flag.argtypes = [vp, i32]
     L.rt_render_frame.argtypes = [vp, i32, i32, vp, C.POINTER(T.FrameStats)]
     L.rt_render_frame_ids.argtypes = [vp, i32, i32, vp, vp, vp, C.POINTER(T.FrameStats)]
     L.rt_render_device.argtypes = [vp, i32, i32, vp, vp]
@@ -101,6 +102,9 @@ class Renderer:
     def set_state(self, camera, config, dynamic=None):
         _check(lib().rt_update_frame_state(self._ctx, C.byref(camera), C.byref(config),
                                            C.byref(dynamic) if dynamic is not None else None))
+
+    def set_strict_octree_flag(self, strict):
+        _check(lib().rt_set_strict_octree_flag(self._ctx, 1 if strict else 0))
 
     def render(self, width, height):
         """Returns (rgb uint8 [h, w, 3], FrameStats)."""

@@ -100,6 +100,7 @@ struct rt_ctx {
     float* hPathCams = nullptr;          // pinned staging copy of the same (the asynchronous copy reads it after the call returns)
     hipEvent_t pathCamsFree = nullptr;   // recorded after the copy out of hPathCams: the next path call waits for it before refilling
     rt::StaticScratch* staticScratch = nullptr;   // this device's record of the never-allocated scratch (rt_render_device_static)
+    bool strictOctreeFlag = false;   // config.octree hides meshes, as the reference's unfinished branch does
     bool forceDeviceBuild = false;   // RT_DEVICE_BUILD=1: build every scene's octrees on the GPU
     // what rt_validate_scene_device needs besides the device arrays
     std::vector<uint32_t> mdlInfoHost;
@@ -531,7 +532,7 @@ int rt_update_frame_state(rt_ctx* ctx, const rt_camera* cam, const rt_config* cf
     else if (cfg->eightBoundingBoxes) p.meshMode = rt::kMeshEightBoxes;
     else if (cfg->boundingBox) p.meshMode = rt::kMeshWholeBox;
     else p.meshMode = rt::kMeshNoBox;
-    f |= rt::kCfgModelsVisible;
+    if (!(cfg->octree && ctx->strictOctreeFlag)) f |= rt::kCfgModelsVisible;
     p.flags = f;
 
     // The dynamic block only rewrites host copies here.  The light travels by value with every launch (DevScene::lightPos);
@@ -552,6 +553,12 @@ int rt_update_frame_state(rt_ctx* ctx, const rt_camera* cam, const rt_config* cf
         }
     }
     ctx->haveState = true;
+    return RT_OK;
+}
+
+int rt_set_strict_octree_flag(rt_ctx* ctx, int strict) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    ctx->strictOctreeFlag = strict != 0;
     return RT_OK;
 }
 

@@ -73,6 +73,15 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene);
 int rt_update_frame_state(rt_ctx* ctx, const rt_camera* cam, const rt_config* config, const rt_dynamic* dyn);
 
 /*
+ * What config.octree = true means.  In the reference that branch of Model::hit is an unfinished stub that returns false
+ * (Model.cpp:163-219), so the flag hides every mesh and its shadows.  By default the library deviates: the flag selects the
+ * whole-model box gate with the octree as accelerator, i.e. meshes render as with boundingBox = true.  strict != 0 restores
+ * the reference's behaviour for this context (meshes invisible while the flag is set).  Takes effect with the next
+ * rt_update_frame_state.
+ */
+int rt_set_strict_octree_flag(rt_ctx* ctx, int strict);
+
+/*
  * Renders one width x height frame and copies it to rgb_out (host, 3*width*height bytes, row-major, RGB8).
  * Replaces RayTracer::launchKernel (RayTracer.cpp:405-417) plus the host read of the managed framebuffer
  * (Window.cpp:414).  stats may be NULL.

@@ -268,6 +268,22 @@ def test_octree_flag_renders_meshes_with_whole_box_semantics(renderer, oracle):
     assert np.array_equal(base, flagged)
 
 
+def test_strict_octree_flag_hides_meshes_like_the_reference(renderer, oracle):
+    """rt_set_strict_octree_flag: config.octree = true then hides every mesh and its shadows (Model.cpp:163-219 returns false),
+    which is what the oracle restates; ids, distances and pixels must match it."""
+    spec, cfg, _, _ = scenes.config_scene(2, detail=0.3)
+    cfg.octree = 1
+    renderer.set_strict_octree_flag(True)
+    try:
+        stats, st, o_rays = _run(renderer, oracle, spec, cfg, 192, 108)
+        assert_parity(stats, st.rays, o_rays)
+        assert stats["id_mismatch"] == 0 and stats["t_bit_mismatch"] == 0
+        rgb, ids, t, _ = renderer.render_ids(192, 108)
+        assert (ids[..., 0] >> 24 == 4).sum() == 0
+    finally:
+        renderer.set_strict_octree_flag(False)
+
+
 @pytest.mark.parametrize("mode", ["whole", "eight"])
 def test_gate_boxes_cutting_through_meshes_on_exact_pixel_rays(renderer, oracle, mode):
     """The gates decide from reciprocal-multiplied quotients when the outcome is clear and divide only near a box edge.
