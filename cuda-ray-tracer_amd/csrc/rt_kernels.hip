@@ -237,11 +237,12 @@ struct SectionTimer {
 
 // ---------------------------------------------------------------- octree traversal
 
-// Reorders the 8 child bits so that bit k is child k ^ oct (front-to-back for a ray whose negative axes are oct).
+// Reorders the 8 child bits of each byte of m so that bit k is child k ^ oct (front-to-back for a ray whose negative axes
+// are oct).  All four bytes are permuted alike, so several masks go through in one call.
 RT_DEV uint32_t permuteOctants(uint32_t m, uint32_t oct) {
-    if (oct & 1u) m = ((m & 0x55u) << 1) | ((m & 0xAAu) >> 1);
-    if (oct & 2u) m = ((m & 0x33u) << 2) | ((m & 0xCCu) >> 2);
-    if (oct & 4u) m = ((m & 0x0Fu) << 4) | ((m & 0xF0u) >> 4);
+    if (oct & 1u) m = ((m & 0x55555555u) << 1) | ((m & 0xAAAAAAAAu) >> 1);
+    if (oct & 2u) m = ((m & 0x33333333u) << 2) | ((m & 0xCCCCCCCCu) >> 2);
+    if (oct & 4u) m = ((m & 0x0F0F0F0Fu) << 4) | ((m & 0xF0F0F0F0u) >> 4);
     return m;
 }
 
@@ -482,21 +483,24 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 const uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
                 if (STATS) { cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask); cnt.nodeVisits++; }
                 childBase = meta.x; childImask = nodeImask;
-                childHits = permuteOctants(hmask & nodeImask, oct);
-                pend = permuteOctants(hmask & nodeLmask, oct);
+                // meta.y holds the internal mask in byte 0 and the leaf mask in byte 1: both are permuted at once
+                const uint32_t both = permuteOctants((hmask | (hmask << 8)) & meta.y & 0xffffu, oct);
+                childHits = both & 0xffu;
+                pend = both >> 8;
                 // the leaf references are fetched only by the lanes that hit a leaf (the line is in the L1 by now)
                 if (pend != 0u) { ra = *reinterpret_cast<const u4_t*>(np + 5); rb = *reinterpret_cast<const u4_t*>(np + 6); }
             }
             // While the pool holds fewer entries than the wave has lanes, every hit child gets an entry of its own (farthest
             // first, so that the nearest ends up on top) and the next turn visits siblings side by side instead of one per turn.
             bool expand = false;
-            if (trav & kTravExpandSiblings) {
+            // (the limit is checked first: a pool that is already larger cannot qualify, and the eight ballots are skipped)
+            const uint32_t expandLimit = min(((trav >> 8) & 0xffu) * 8u, nodeCapacity - 24u);
+            if ((trav & kTravExpandSiblings) && nodeCount <= expandLimit) {
                 uint32_t total = nodeCount;
 #pragma unroll
                 for (int k = 0; k < 8; k++) total += (uint32_t)__builtin_popcountll(__ballot(((childHits >> k) & 1u) != 0u));
                 // the entries written below end before position `total`: never beyond the pool, whatever limit the caller set
-                const uint32_t limit = ((trav >> 8) & 0xffu) * 8u;
-                expand = total <= (limit < nodeCapacity - 24u ? limit : nodeCapacity - 24u);
+                expand = total <= expandLimit;
             }
             if (expand) {
                 uint32_t waiting = childHits;

@@ -8,7 +8,7 @@ import sys
 from collections import defaultdict
 
 out_dir = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
-kernel = sys.argv[2] if len(sys.argv) > 2 else "renderKernel<false>"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "renderKernel<false"      # every variant of the plain (uninstrumented) render kernel
 acc = defaultdict(list)
 for path in glob.glob(os.path.join(out_dir, "*", "**", "*counter_collection.csv"), recursive=True):
     with open(path) as f:
