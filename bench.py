@@ -493,7 +493,7 @@ def main():
             try:
                 with open(tpath) as f:
                     tj = json.load(f)
-                if tj.get("workload") == f"config{args.config}" and world == 1 and (w, h) == tuple(tj.get("size", ())):
+                if tj.get("workload") == f"config{args.config}" and world == 1 and (w, h) == tuple(tj.get("size", ())) and (args.config != 5 or abs(args.detail - 7.0) < 1e-9):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
