@@ -671,8 +671,18 @@ int renderPath(rt_ctx* ctx, int width, int height, int rank, int world, bool com
         RT_HIP(rt::launchRenderPath(ctx->scene, p, out, frameBytes, nFrames, ctx->dPathCams, stream, nullptr, nullptr));
         return RT_OK;
     }
-    // same two-buffer scheme as launchOrdered; the block feedback for split waves is left alone (nothing is split here)
-    if (!plan.haveOrder) RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2, stream));
+    // same two-buffer scheme as launchOrdered.  Nothing is split here, but a change of frame geometry must also forget the
+    // blocks chosen for the old one: a later single-frame launch of this geometry would otherwise find an order in place and
+    // trust a split list that indexes another frame's blocks.
+    if (!plan.haveOrder) {
+        RT_HIP(hipMemsetAsync(ctx->dTileCost, 0, sizeof(uint32_t) * kMaxOrderedTiles * 2, stream));
+        const int blocks = p.ownedTiles * (RT_TILE / 8) * (RT_TILE / 8);
+        if (ctx->split > 0 && blocks <= rt::kMaxSplitBlocks) {
+            RT_HIP(hipMemsetAsync(ctx->dBlockCost, 0, sizeof(uint32_t) * (size_t)blocks, stream));
+            RT_HIP(hipMemsetAsync(ctx->dSplitState, 0, sizeof(rt::SplitState), stream));
+        }
+        ctx->framesSinceSelection = 0;
+    }
     uint32_t* cur = ctx->dTileCost + (size_t)ctx->costSlot * kMaxOrderedTiles;
     uint32_t* nxt = ctx->dTileCost + (size_t)(ctx->costSlot ^ 1) * kMaxOrderedTiles;
     RT_HIP(rt::launchRenderPath(ctx->scene, p, out, frameBytes, nFrames, ctx->dPathCams, stream, plan.haveOrder ? ctx->dTileOrder : nullptr, cur));

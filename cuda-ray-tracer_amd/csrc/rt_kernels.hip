@@ -1023,6 +1023,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
             const uint32_t blk = e & 0xFFFFFu;
             sub = (e >> 20) & 7u;
             localTile = blk / (uint32_t)kWavesPerTile; inTile = blk % (uint32_t)kWavesPerTile;
+            if (localTile >= (uint32_t)P.ownedTiles) retire = true;      // a split list is only ever used for the geometry it was made for; never render outside it
         } else { localTile = 0; inTile = 0; retire = true; }
     } else {
         const uint32_t b = waveIndex;

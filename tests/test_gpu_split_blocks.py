@@ -77,3 +77,28 @@ def test_split_tile_sharded_frame(split_renderer):
     split_renderer.untile_device(w, h, world, gathered.data_ptr(), frame.data_ptr(), stream)
     torch.cuda.synchronize()
     assert np.array_equal(direct, frame.cpu().numpy().reshape(h, w, 3))
+
+
+def test_geometry_change_through_a_path_launch_forgets_the_split_list(split_renderer):
+    """A context that splits blocks of one frame size, then renders a camera path at another size, then single frames at
+    that size: the split list made for the first size must not be used for the second (it indexes other blocks)."""
+    import torch
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.2)
+    built = scenes.build_scene(spec)
+    split_renderer.upload(built.desc)
+    split_renderer.set_state(built.camera, cfg)
+    for _ in range(3):
+        big, _ = split_renderer.render(640, 360)          # blocks of the large frame are split from the second frame on
+    w, h = 160, 96
+    stream = torch.cuda.current_stream().cuda_stream
+    frames = torch.zeros(2 * w * h * 3, dtype=torch.uint8, device="cuda:0")
+    guard = torch.full((1 << 20,), 77, dtype=torch.uint8, device="cuda:0")      # allocated right behind: must stay untouched
+    split_renderer.render_path_device(w, h, [built.camera, built.camera], frames.data_ptr(), stream)
+    small = torch.zeros(w * h * 3, dtype=torch.uint8, device="cuda:0")
+    for _ in range(3):
+        split_renderer.render_device(w, h, small.data_ptr(), stream)
+    torch.cuda.synchronize()
+    ref, _ = split_renderer.render(w, h)
+    assert np.array_equal(small.cpu().numpy().reshape(h, w, 3), ref)
+    assert np.array_equal(frames.cpu().numpy()[:w * h * 3].reshape(h, w, 3), ref)
+    assert bool((guard == 77).all())
