@@ -86,6 +86,27 @@ double Headless::measure(int frames) {
     return averageRenderTime;
 }
 
+double Headless::runSequence(int frames, const std::string& keys, const std::string& directory) {
+    double total = 0.0;
+    for (int i = 0; i < frames; i++) {
+        if (!keys.empty()) {
+            const char k = keys[(size_t)i % keys.size()];
+            if (k == '<') rayTracer.scene.cam.mouseMovement(-20.0, 0.0);
+            else if (k == '>') rayTracer.scene.cam.mouseMovement(20.0, 0.0);
+            else if (k != ' ') keyHeld(k);
+        }
+        display();
+        total += lastRenderTime;
+        if (!directory.empty()) {
+            char name[32];
+            std::snprintf(name, sizeof name, "/frame_%04d.ppm", i);
+            if (!writePPM(directory + name)) return -1.0;
+        }
+    }
+    averageRenderTime = frames > 0 ? total / frames : 0.0;
+    return averageRenderTime;
+}
+
 bool Headless::writePPM(const std::string& path) const {
     FILE* f = std::fopen(path.c_str(), "wb");
     if (!f) return false;

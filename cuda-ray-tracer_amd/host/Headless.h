@@ -23,6 +23,11 @@ public:
     void display();
     // Renders `frames` frames and returns the average render time in seconds (Window.cpp:406-412).
     double measure(int frames);
+    // The frame loop with input (Window::run + Window::display, Window.cpp:215-326, 338-421): before frame i the key keys[i % n]
+    // is held for one frame (see keyHeld; '<' and '>' turn the camera by 20 mouse units, ' ' holds nothing), then the frame is
+    // rendered; with a directory, every frame is written there as frame_0000.ppm, frame_0001.ppm, ...  Returns the average
+    // render time in seconds, or a negative value if a frame could not be written.
+    double runSequence(int frames, const std::string& keys, const std::string& directory);
 
     bool writePPM(const std::string& path) const;
 };

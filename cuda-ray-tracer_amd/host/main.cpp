@@ -1,5 +1,9 @@
 // rt_headless: the reference's main() (main.cpp:11-23) without a window.
 //   rt_headless [--size WxH] [--preset KEY] [--frames N] [--models DIR] [--out frame.ppm] [--device N] [--gpus N] [--sharded]
+//               [--keys STRING] [--sequence DIR]
+// --keys holds one movement key per frame, cyclically (w a s d _ | move the camera, i j k l u o the light, < > turn the
+// camera, a blank nothing): the reference's interactive frame loop without the window.  --sequence writes every frame of
+// the run into DIR as frame_0000.ppm, ...
 // Renders the preset's scene N times (default 100, as the reference's render-time average) and prints the timing.
 // --gpus N shards every frame by image tiles over GPUs 0 .. N-1 of this node: one process per GPU (forked before anything
 // touches a GPU), each with its own copy of the scene; the tiles are gathered to rank 0 over RCCL and rank 0 reports.
@@ -34,7 +38,7 @@ bool writeAll(int fd, const void* buf, size_t n) {
 int main(int argc, char** argv) {
     int width = 1000, height = 1000, frames = 100, device = 0, gpus = 1;   // main.cpp:13 opens a 1000x1000 window
     bool sharded = false;
-    std::string models = "assets/models", out;
+    std::string models = "assets/models", out, keys, sequence;
     char preset = 'Z';
     for (int i = 1; i < argc; i++) {
         auto next = [&]() -> const char* { return i + 1 < argc ? argv[++i] : ""; };
@@ -46,6 +50,8 @@ int main(int argc, char** argv) {
         else if (!std::strcmp(argv[i], "--device")) device = std::atoi(next());
         else if (!std::strcmp(argv[i], "--gpus")) gpus = std::atoi(next());
         else if (!std::strcmp(argv[i], "--sharded")) sharded = true;
+        else if (!std::strcmp(argv[i], "--keys")) keys = next();
+        else if (!std::strcmp(argv[i], "--sequence")) sequence = next();
         else { std::fprintf(stderr, "unknown argument %s\n", argv[i]); return 2; }
     }
     if (gpus < 1 || gpus > 64) { std::fprintf(stderr, "--gpus 1 .. 64\n"); return 2; }
@@ -94,7 +100,9 @@ int main(int argc, char** argv) {
             };
         }
         if (!app.keyPreset(preset)) { std::fprintf(stderr, "unknown preset key '%c' (Z X C V B N M , .)\n", preset); return 2; }
-        double avg = app.measure(frames);
+        const bool moving = !keys.empty() || !sequence.empty();
+        double avg = moving ? app.runSequence(frames, keys, rank == 0 ? sequence : std::string()) : app.measure(frames);
+        if (avg < 0.0) { std::fprintf(stderr, "cannot write into %s\n", sequence.c_str()); status = 1; avg = 0.0; }
         if (rank == 0) {
             if (comm) std::printf("Average render time: %f over %d renders on %d GPUs (image tiles, RCCL gather to rank 0)\n", avg, frames, gpus);
             else std::printf("Average render time: %f over %d renders (last frame: %.3f ms on the GPU, %llu rays, %.1f Mrays/s)\n", avg, frames,

@@ -212,3 +212,22 @@ def test_headless_driver_sharded_path_writes_the_same_frame(model_dir, tmp_path)
         assert "Average render time" in res.stdout
         outs.append(out.read_bytes())
     assert len(outs[0]) > 333 * 201 * 3 and outs[0] == outs[1]
+
+
+@pytest.mark.gpu
+def test_headless_frame_loop_with_keys_writes_a_sequence(model_dir, tmp_path):
+    """rt_headless --keys / --sequence: the reference's interactive loop (keys move camera and light between launches,
+    Window.cpp:339-380) without the window; every frame lands on disk, consecutive frames differ, and the last frame of the
+    sequence is the frame --out writes."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(host_lib.HOST_SO), "rt_headless")
+    seq = tmp_path / "seq"; seq.mkdir()
+    out = tmp_path / "last.ppm"
+    cmd = [exe, "--size", "200x120", "--preset", ".", "--frames", "6", "--models", model_dir, "--keys", "wd<jj ", "--sequence", str(seq), "--out", str(out)]
+    res = subprocess.run(cmd, capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0, res.stderr[-2000:]
+    frames = [(seq / ("frame_%04d.ppm" % i)).read_bytes() for i in range(6)]
+    assert all(len(f) > 200 * 120 * 3 for f in frames)
+    assert frames[0] != frames[1] and frames[2] != frames[3] and frames[3] != frames[4]
+    assert frames[4] == frames[5]                       # the blank key holds nothing: the same frame again
+    assert frames[5] == out.read_bytes()
