@@ -264,6 +264,18 @@ RT_DEV SlabRay makeSlabRay(V3 o, V3 d) {
     return r;
 }
 
+// Sum of v over the 64 lanes of the wave, all of which must be active: four shifts within the rows of sixteen lanes, then the
+// row totals are passed on to the next row and to the upper half; lane 63 ends up with the total.
+RT_DEV uint32_t waveSum(uint32_t v) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, true);   // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xf, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xf, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, true);   // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, true);   // row_bcast:31 into rows 2 and 3
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
+}
+
 RT_DEV float byteToFloat(uint32_t w, int k) { return (float)((w >> (8 * k)) & 0xffu); }   // v_cvt_f32_ubyte<k>
 
 // Four children at once.  n* / f* hold the quantised entry / exit planes of the four children on each axis (one byte
@@ -449,8 +461,10 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 if (again) lds.nodePool[nodeCount + rank] = (unsigned long long)base | ((unsigned long long)(imask | (rest << 8) | (owner << 16) | (chunkMask << 24)) << 32);
                 nodeCount += (uint32_t)__builtin_popcountll(m);
             }
-            uint32_t childHits = 0, pend = 0, childBase = 0, childImask = 0, oct = 0;
-            u4_t ra = {0, 0, 0, 0}, rb = {0, 0, 0, 0};
+            // childBase, childImask and oct are read only where childHits or pend is not zero, ra and rb only where pend is not
+            // zero - all of which a lane sets below if at all (no start values: they would be written by every lane every turn)
+            uint32_t childHits = 0, pend = 0, childBase, childImask, oct;
+            u4_t ra, rb;
             if (alive) {
                 const f4_t ro4 = lds.rayO[owner], rr4 = lds.rayR[owner];
                 const V3 ro = xyz(ro4);
@@ -496,9 +510,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             // (the limit is checked first: a pool that is already larger cannot qualify, and the eight ballots are skipped)
             const uint32_t expandLimit = min(((trav >> 8) & 0xffu) * 8u, nodeCapacity - 24u);
             if ((trav & kTravExpandSiblings) && nodeCount <= expandLimit) {
-                uint32_t total = nodeCount;
-#pragma unroll
-                for (int k = 0; k < 8; k++) total += (uint32_t)__builtin_popcountll(__ballot(((childHits >> k) & 1u) != 0u));
+                const uint32_t total = nodeCount + waveSum((uint32_t)__builtin_popcount(childHits));
                 // the entries written below end before position `total`: never beyond the pool, whatever limit the caller set
                 expand = total <= expandLimit;
             }
@@ -533,7 +545,11 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                     const uint32_t k = 31u - (uint32_t)__builtin_clz(pend);
                     pend &= ~(1u << k);
                     const uint32_t lc = k ^ oct;
-                    const uint32_t start = lc == 0 ? ra.x : lc == 1 ? ra.y : lc == 2 ? ra.z : lc == 3 ? ra.w : lc == 4 ? rb.x : lc == 5 ? rb.y : lc == 6 ? rb.z : rb.w;
+                    // three levels of selects on the bits of lc (a chain of comparisons becomes a tree of branches)
+                    const bool b0 = (lc & 1u) != 0u, b1 = (lc & 2u) != 0u, b2 = (lc & 4u) != 0u;
+                    const uint32_t s01 = b0 ? ra.y : ra.x, s23 = b0 ? ra.w : ra.z, s45 = b0 ? rb.y : rb.x, s67 = b0 ? rb.w : rb.z;
+                    const uint32_t s03 = b1 ? s23 : s01, s47 = b1 ? s67 : s45;
+                    const uint32_t start = b2 ? s47 : s03;
                     lds.triPool[triCount + rank] = (unsigned long long)start | ((unsigned long long)(owner | (chunkMask << 8)) << 32);
                 }
                 triCount += (uint32_t)__builtin_popcountll(m);
