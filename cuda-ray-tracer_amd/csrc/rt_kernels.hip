@@ -31,7 +31,19 @@ typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 #define RT_DEV __device__ __forceinline__
 constexpr int kBlockThreads = 64;   // render workgroups are single waves
 constexpr uint32_t kSplitGainNum = 5, kSplitGainDen = 3;   // a block rendered by eight split waves is taken to finish 5/3 times sooner (measured: 1.65)
-constexpr int kNodePool = 512;       // mesh traversal: entries of pending children per wave
+// Occupancy of the render kernel: four waves per SIMD (128 registers; what does not fit is spilled around the traces, not
+// inside them) with 10 KB of LDS per wave - measured 5 % faster than three waves with 168 registers and 12.4 KB, although the
+// node pool is smaller and the reciprocal direction is recomputed per entry instead of kept in LDS.
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4
+#endif
+#ifndef RT_NODE_POOL_ENTRIES
+#define RT_NODE_POOL_ENTRIES 368
+#endif
+#ifndef RT_RCP_IN_LDS
+#define RT_RCP_IN_LDS 0
+#endif
+constexpr int kNodePool = RT_NODE_POOL_ENTRIES;       // mesh traversal: entries of pending children per wave
 constexpr int kTriPool = 560;        // and of pending triangle runs (a node turn can add 8 per lane to fewer than 40)
 constexpr int kDirectStartModels = 6;  // up to this many models a trace can start at the model roots (one pool entry per ray and model)
 constexpr int kExactRankTiles = 4096;  // up to this many tiles are ranked by all-pairs comparison
@@ -409,7 +421,8 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
         f4_t ro4 = {o.x, o.y, o.z, ubits((uint32_t)gateBits)}, rd4 = {d.x, d.y, d.z, ubits((uint32_t)(gateBits >> 32))};
         const SlabRay own = makeSlabRay(o, d);
         f4_t rr4 = {own.rd.x, own.rd.y, own.rd.z, ubits(own.oct)};
-        lds.rayO[lane] = ro4; lds.rayD[lane] = rd4; lds.rayR[lane] = rr4;
+        lds.rayO[lane] = ro4; lds.rayD[lane] = rd4;
+        if (RT_RCP_IN_LDS) lds.rayR[lane] = rr4;
         lds.bestKey[lane] = init;
     }
     // one pseudo entry per ray that resolves to the forest root
@@ -466,10 +479,17 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             uint32_t childHits = 0, pend = 0, childBase, childImask, oct;
             u4_t ra, rb;
             if (alive) {
-                const f4_t ro4 = lds.rayO[owner], rr4 = lds.rayR[owner];
+                const f4_t ro4 = lds.rayO[owner];
                 const V3 ro = xyz(ro4);
                 SlabRay sr;
-                sr.rd = xyz(rr4); sr.o = ro; sr.oct = fbits(rr4.w);
+                f4_t rdHere = {0, 0, 0, 0};
+                if (RT_RCP_IN_LDS) {
+                    const f4_t rr4 = lds.rayR[owner];
+                    sr.rd = xyz(rr4); sr.o = ro; sr.oct = fbits(rr4.w);
+                } else {
+                    rdHere = lds.rayD[owner];
+                    sr = makeSlabRay(ro, xyz(rdHere));
+                }
                 oct = sr.oct;
                 const uint32_t c = (uint32_t)__builtin_ctz(hits) ^ oct;
                 const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
@@ -479,7 +499,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 uint32_t hmask = testChildren(np, head, sr, tmin, tmax);
                 if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
                     const int mm = (int)meta.z;
-                    const f4_t rd4 = lds.rayD[owner];
+                    const f4_t rd4 = RT_RCP_IN_LDS ? lds.rayD[owner] : rdHere;
                     const V3 rdir = xyz(rd4);
                     const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
                     const unsigned long long bits = (unsigned long long)fbits(ro4.w) | ((unsigned long long)fbits(rd4.w) << 32);
@@ -980,7 +1000,7 @@ __host__ __device__ inline uint32_t wavesPerFrame(const FrameParams& P) {
 // of FrameParams::camPos .. eyeDir) into out + f * pathFrameBytes.  Frames follow each other in dispatch order, so the first
 // waves of frame f + 1 fill the GPU while the slow tail of frame f drains.  Nothing is split in this mode.
 template <bool STATS, bool PATH = false>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3))) void renderKernel(DevScene sceneArg, FrameParams frameArg, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_SIMD))) void renderKernel(DevScene sceneArg, FrameParams frameArg, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
                                                     float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
                                                     unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
                                                     uint32_t* __restrict__ tileCost, BlockFeedback fb,
@@ -1017,7 +1037,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(3
     const uint32_t waveIndex = blockIndex < lead ? blockIndex : blockIndex - (splitWave ? lead : extraWaves);    // among the waves of its kind
     // 12416 bytes per wave: twelve waves per CU (three per SIMD) fit the 160 KB of LDS.  Measured: at 12928 bytes fewer
     // waves are resident and the frame takes 7 % longer.
-    __shared__ f4_t poolRays[3 * kBlockThreads];
+    __shared__ f4_t poolRays[(RT_RCP_IN_LDS ? 3 : 2) * kBlockThreads];
     __shared__ unsigned long long poolBest[kBlockThreads];
     __shared__ uint32_t poolRec[kBlockThreads];
     __shared__ unsigned long long poolNodes[kNodePool];
