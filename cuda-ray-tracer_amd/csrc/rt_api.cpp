@@ -322,7 +322,8 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     c->device = devices[0];
     if (const char* e = std::getenv("RT_BLOCK_ORDER")) c->blockOrder = std::atoi(e);   // experiment switches
     if (const char* e = std::getenv("RT_COST_ORDER")) c->costOrdering = std::atoi(e) != 0;
-    if (const char* e = std::getenv("RT_NODE_POOL")) c->nodePoolEntries = std::atoi(e);    // tests: forces the traversal's low-room path
+    if (const char* e = std::getenv("RT_NODE_POOL")) c->nodePoolEntries = std::atoi(e) & 0xffff;    // tests: forces the traversal's low-room path
+    if (const char* e = std::getenv("RT_TRI_POOL")) c->nodePoolEntries |= (std::atoi(e) & 0xffff) << 16;  // the same for the pool of triangle work
     if (const char* e = std::getenv("RT_TRAV")) c->traversal = std::atoi(e) & 0xffff;   // the kernel caps the expansion limit at its pool size
     if (const char* e = std::getenv("RT_LEAD_WAVES")) { const int v = std::atoi(e); if (v >= 0) c->leadWaves = (v + 7) / 8 * 8; }
     if (const char* e = std::getenv("RT_DEVICE_BUILD")) c->forceDeviceBuild = std::atoi(e) != 0;

@@ -96,7 +96,7 @@ struct FrameParams {
     int32_t rank, world, tilesX, tilesY, ownedTiles;
     int32_t compactOutput;     // 1: write tile-major into the rank's compact buffer, 0: row-major full frame
     int32_t blockOrder;        // workgroup -> tile mapping: 0 tile by tile, 2 tiles interleaved over the XCDs
-    int32_t nodePoolEntries;   // capacity of the traversal's pool of pending children that a wave may use (96 .. the compiled size; smaller values only serve tests)
+    int32_t nodePoolEntries;   // low half: capacity of the traversal's pool of pending children that a wave may use (96 .. the compiled size), high half: of its pool of triangle work (72 .. compiled size); 0 = compiled size, smaller values only serve tests
     int32_t traversal;         // kTrav* bits; bits 8-15: sibling expansion applies while the pool holds at most 8 x this many entries
     int32_t leadWaves;         // with split: this many regular waves (a multiple of 8) come before the split waves in the grid
     int32_t split;             // 1: the grid starts with kMaxExtraWaves split waves for the heaviest blocks (BlockFeedback::extraMap)

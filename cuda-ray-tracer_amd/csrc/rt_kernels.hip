@@ -38,13 +38,17 @@ constexpr uint32_t kSplitGainNum = 5, kSplitGainDen = 3;   // a block rendered b
 #define RT_WAVES_PER_SIMD 4
 #endif
 #ifndef RT_NODE_POOL_ENTRIES
-#define RT_NODE_POOL_ENTRIES 368
+#define RT_NODE_POOL_ENTRIES 512
 #endif
 #ifndef RT_RCP_IN_LDS
-#define RT_RCP_IN_LDS 0
+#define RT_RCP_IN_LDS 1
 #endif
 constexpr int kNodePool = RT_NODE_POOL_ENTRIES;       // mesh traversal: entries of pending children per wave
-constexpr int kTriPool = 560;        // and of pending triangle runs (a node turn can add 8 per lane to fewer than 40)
+constexpr int kTriPool = 288;        // and of pending triangle work: runs of triangles, and sets of leaves of one node
+constexpr uint32_t kLeafSet = 1u << 27;   // triangle pool entry, high word: owner | chunks << 8 | (leaf set: hit mask << 16 | octant << 24 | kLeafSet)
+#ifndef RT_TRI_TURN_AT
+#define RT_TRI_TURN_AT 40u
+#endif
 constexpr int kDirectStartModels = 6;  // up to this many models a trace can start at the model roots (one pool entry per ray and model)
 constexpr int kExactRankTiles = 4096;  // up to this many tiles are ranked by all-pairs comparison
 constexpr int kWaveRecordWords = 18; // per-wave diagnostic record: start, end, 8 x (cycles, executions)
@@ -70,6 +74,12 @@ RT_DEV float selMax(float x, float y) { return (x > y) ? x : y; }   // utils.h:9
 RT_DEV float selMin(float x, float y) { return (x < y) ? x : y; }   // utils.h:86-88
 
 RT_DEV f4_t ld4(const F4* p) { return *reinterpret_cast<const f4_t*>(p); }
+// Loads at an address that is the same for the whole wave, from tables nothing writes while a render kernel runs (the scene's
+// object tables): through the constant address space, so that the scalar unit fetches them (its cache holds these few hundred
+// bytes for good, and the values arrive in scalar registers) instead of 64 lanes asking the vector cache for one address.
+RT_DEV f4_t ldu4(const F4* p) { return *(const __attribute__((address_space(4))) f4_t*)(unsigned long long)p; }
+RT_DEV uint32_t lduw(const uint32_t* p) { return *(const __attribute__((address_space(4))) uint32_t*)(unsigned long long)p; }
+RT_DEV uint32_t lduFlags(const F4* p) { return lduw(reinterpret_cast<const uint32_t*>(p) + 3); }     // the w word of a table entry
 RT_DEV uint32_t fbits(float f) { return __float_as_uint(f); }
 RT_DEV float ubits(uint32_t u) { return __uint_as_float(u); }
 
@@ -228,7 +238,7 @@ struct WaveLds {
     unsigned long long* bestKey;         // [64] ordered hit distance << 32 | triangle order key (see tracePool)
     uint32_t* bestRec;                   // [64] triangle record of the hit in bestKey
     unsigned long long* nodePool;        // [kNodePool] pending children: node base | (imask | hits << 8 | owner << 16 | chunks << 24) << 32
-    unsigned long long* triPool;         // [kTriPool] pending triangles: first record | (owner | chunks << 8) << 32
+    unsigned long long* triPool;         // [kTriPool] pending triangles: first record | (owner | chunks << 8) << 32, or a node's leaf set (kLeafSet)
     unsigned long long* prof;   // instrumented kernel only: 8 per-wave accumulators in LDS (see renderKernel)
 };
 
@@ -379,8 +389,9 @@ RT_DEV float orderFloat(uint32_t m) { return ubits((m & 0x80000000u) ? (m & 0x7f
 // level) until there is room again.  A node turn adds at most eight triangle runs per
 // lane, and is only taken with fewer than 40 runs pending.
 template <bool ANYHIT, bool STATS>
-RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t nodeCapacity, uint32_t trav, Closest& best, WaveLds lds, Counters& cnt) {
+RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t poolCapacity, uint32_t trav, Closest& best, WaveLds lds, Counters& cnt) {
     if (S.forestRoot == kNoRoot) return false;
+    const uint32_t nodeCapacity = poolCapacity & 0xffffu, triCapacity = poolCapacity >> 16;
     SectionTimer<STATS> timerWhole;
     const uint32_t lane = threadIdx.x & 63u;
     const int nMdl = S.nMdl;
@@ -390,11 +401,13 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
 
     // Is model mm a candidate for the ray at all: not hidden from this ray type, and (whole-box mode) through the
     // reference's exact bounding-box gate.
-    auto gate = [&](int mm, V3 ro, V3 rdir, V3 rrd, bool fin) -> bool {
-        if ((skipDebug || ANYHIT) && (fbits(S.mdlMat[3 * mm + 2].w) & 1u)) return false;
+    // (uniform: mm is the same for the whole wave)
+    auto gate = [&](int mm, V3 ro, V3 rdir, V3 rrd, bool fin, const bool uniform) -> bool {
+        if ((skipDebug || ANYHIT) && ((uniform ? lduFlags(S.mdlMat + 3 * mm + 2) : fbits(S.mdlMat[3 * mm + 2].w)) & 1u)) return false;
         if (meshMode == kMeshWholeBox) {
             if (STATS) cnt.gateTests++;
-            return boxHitDecision(xyz(ld4(S.mdlGateMin + mm)), xyz(ld4(S.mdlGateMax + mm)), ro, rdir, rrd, fin);
+            const f4_t lo = uniform ? ldu4(S.mdlGateMin + mm) : ld4(S.mdlGateMin + mm), hi = uniform ? ldu4(S.mdlGateMax + mm) : ld4(S.mdlGateMax + mm);
+            return boxHitDecision(xyz(lo), xyz(hi), ro, rdir, rrd, fin);
         }
         return true;
     };
@@ -410,8 +423,8 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
         const SlabRay sr = makeSlabRay(o, d);
         const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
         for (int j = 0; j < nMdl; j++) {
-            if (!tightBoxHit(xyz(ld4(S.mdlTightMin + j)), xyz(ld4(S.mdlTightMax + j)), sr, tmin, startT)) continue;
-            if (gate(j, o, d, sr.rd, fin)) gateBits |= 1ull << j;
+            if (!tightBoxHit(xyz(ldu4(S.mdlTightMin + j)), xyz(ldu4(S.mdlTightMax + j)), sr, tmin, startT)) continue;
+            if (gate(j, o, d, sr.rd, fin, true)) gateBits |= 1ull << j;
         }
         timerG.stop(lds, 2);
     }
@@ -431,7 +444,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
         // few models, gates known: one entry per ray and model whose gate the ray passed, resolving to that model's root
         nodeCount = 0;
         for (int j = 0; j < nMdl; j++) {
-            const uint32_t root = S.mdlInfo[4 * j];
+            const uint32_t root = lduw(S.mdlInfo + 4 * j);
             const bool in = enters && ((gateBits >> j) & 1ull) != 0 && root != kNoRoot;
             const unsigned long long m = __ballot(in);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -447,7 +460,8 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
     __builtin_amdgcn_wave_barrier();
 
     while (nodeCount != 0 || triCount != 0) {
-        const bool nodeTurn = nodeCount != 0 && triCount < 40u;    // measured: 16 -> +2 %, 32..48 best, 64 -> +2 % frame time
+        // a node turn adds at most one triangle entry per lane
+        const bool nodeTurn = nodeCount != 0 && triCount < RT_TRI_TURN_AT && triCount + 65u <= triCapacity;
         if (nodeTurn) {
             SectionTimer<STATS> timerA;
             const uint32_t room = nodeCapacity - nodeCount;
@@ -474,10 +488,9 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 if (again) lds.nodePool[nodeCount + rank] = (unsigned long long)base | ((unsigned long long)(imask | (rest << 8) | (owner << 16) | (chunkMask << 24)) << 32);
                 nodeCount += (uint32_t)__builtin_popcountll(m);
             }
-            // childBase, childImask and oct are read only where childHits or pend is not zero, ra and rb only where pend is not
-            // zero - all of which a lane sets below if at all (no start values: they would be written by every lane every turn)
-            uint32_t childHits = 0, pend = 0, childBase, childImask, oct;
-            u4_t ra, rb;
+            // childBase, childImask, oct and visited are read only where childHits or pend is not zero - where a lane has set
+            // them below (no start values: they would be written by every lane every turn)
+            uint32_t childHits = 0, pend = 0, childBase, childImask, oct, visited;
             if (alive) {
                 const f4_t ro4 = lds.rayO[owner];
                 const V3 ro = xyz(ro4);
@@ -493,6 +506,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 oct = sr.oct;
                 const uint32_t c = (uint32_t)__builtin_ctz(hits) ^ oct;
                 const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
+                visited = node;
                 const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
                 const u4_t head = *reinterpret_cast<const u4_t*>(np), meta = *reinterpret_cast<const u4_t*>(np + 1);
                 const float tmax = ANYHIT ? FAR_T : orderFloat((uint32_t)(bk >> 32));
@@ -503,7 +517,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                     const V3 rdir = xyz(rd4);
                     const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
                     const unsigned long long bits = (unsigned long long)fbits(ro4.w) | ((unsigned long long)fbits(rd4.w) << 32);
-                    bool enter = pregated ? (((bits >> mm) & 1ull) != 0) : gate(mm, ro, rdir, sr.rd, fin);
+                    bool enter = pregated ? (((bits >> mm) & 1ull) != 0) : gate(mm, ro, rdir, sr.rd, fin, false);
                     if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
                         chunkMask = 0;
                         for (int b = 0; b < 8; b++) {
@@ -521,8 +535,6 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 const uint32_t both = permuteOctants((hmask | (hmask << 8)) & meta.y & 0xffffu, oct);
                 childHits = both & 0xffu;
                 pend = both >> 8;
-                // the leaf references are fetched only by the lanes that hit a leaf (the line is in the L1 by now)
-                if (pend != 0u) { ra = *reinterpret_cast<const u4_t*>(np + 5); rb = *reinterpret_cast<const u4_t*>(np + 6); }
             }
             // While the pool holds fewer entries than the wave has lanes, every hit child gets an entry of its own (farthest
             // first, so that the nearest ends up on top) and the next turn visits siblings side by side instead of one per turn.
@@ -555,38 +567,49 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 if (down) lds.nodePool[nodeCount + rank] = (unsigned long long)childBase | ((unsigned long long)(childImask | (childHits << 8) | (owner << 16) | (chunkMask << 24)) << 32);
                 nodeCount += (uint32_t)__builtin_popcountll(m);
             }
-            // leaves, farthest first so that the nearest is the newest
-            for (;;) {
-                const bool more = pend != 0u;
-                const unsigned long long m = __ballot(more);
-                if (m == 0ull) break;
+            // the leaves the ray hit in this node: one entry that names the node and the set (lowest bit = nearest leaf); the
+            // triangle turns take the leaves off it one by one and look their triangles up in the node record
+            {
+                const bool has = pend != 0u;
+                const unsigned long long m = __ballot(has);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (more) {
-                    const uint32_t k = 31u - (uint32_t)__builtin_clz(pend);
-                    pend &= ~(1u << k);
-                    const uint32_t lc = k ^ oct;
-                    // three levels of selects on the bits of lc (a chain of comparisons becomes a tree of branches)
-                    const bool b0 = (lc & 1u) != 0u, b1 = (lc & 2u) != 0u, b2 = (lc & 4u) != 0u;
-                    const uint32_t s01 = b0 ? ra.y : ra.x, s23 = b0 ? ra.w : ra.z, s45 = b0 ? rb.y : rb.x, s67 = b0 ? rb.w : rb.z;
-                    const uint32_t s03 = b1 ? s23 : s01, s47 = b1 ? s67 : s45;
-                    const uint32_t start = b2 ? s47 : s03;
-                    lds.triPool[triCount + rank] = (unsigned long long)start | ((unsigned long long)(owner | (chunkMask << 8)) << 32);
-                }
+                if (has) lds.triPool[triCount + rank] = (unsigned long long)visited | ((unsigned long long)(owner | (chunkMask << 8) | (pend << 16) | (oct << 24) | kLeafSet) << 32);
                 triCount += (uint32_t)__builtin_popcountll(m);
             }
             timerA.stop(lds, 0);
         } else {
             SectionTimer<STATS> timerB;
-            const uint32_t take = triCount < 64u ? triCount : 64u;
+            // A lane takes one entry and puts back at most two (the rest of a leaf set, the rest of a run of triangles): a full
+            // turn needs 64 free entries; with fewer, one entry stays free, and in a full pool the newest entry is a run, which
+            // a single lane takes without needing room (see the order of the two pushes below).
+            const uint32_t room = triCapacity - triCount;
+            const uint32_t width = room >= 64u ? 64u : (room >= 2u ? room - 1u : 1u);
+            const uint32_t take = triCount < width ? triCount : width;
             const bool mine = lane < take;
             if (STATS && lane == 0) { lds.prof[14] += take; lds.prof[15] += 1ull + (64ull << 32); }
             unsigned long long e = 0;
             if (mine) e = lds.triPool[triCount - 1u - lane];
             triCount -= take;
-            const uint32_t first = (uint32_t)e, owner = (uint32_t)(e >> 32) & 63u, chunks = (uint32_t)(e >> 40) & 0xffu;
+            const uint32_t lo = (uint32_t)e, hi = (uint32_t)(e >> 32);
+            const uint32_t owner = hi & 63u, chunks = (hi >> 8) & 0xffu;
             unsigned long long bk = 0;
             if (mine) bk = lds.bestKey[owner];
             const bool alive = mine && !(ANYHIT && bk == 0ull);
+            // a leaf set: the nearest leaf is taken now (its first triangle record stands in the node), the others go back
+            uint32_t first = lo, restMask = 0;
+            if (alive && (hi & kLeafSet)) {
+                const uint32_t mask = (hi >> 16) & 0xffu;
+                const uint32_t lc = (uint32_t)__builtin_ctz(mask) ^ ((hi >> 24) & 7u);
+                first = reinterpret_cast<const uint32_t*>(S.nodes + (size_t)lo * kNodeFloat4s + 5)[lc];
+                restMask = mask & (mask - 1u);
+            }
+            {
+                const bool again = restMask != 0u;
+                const unsigned long long m = __ballot(again);
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                if (again) lds.triPool[triCount + rank] = (unsigned long long)lo | ((unsigned long long)((hi & ~(0xffu << 16)) | (restMask << 16)) << 32);
+                triCount += (uint32_t)__builtin_popcountll(m);
+            }
             bool goesOn = false;
             if (alive) {
                 const F4* tp = S.tris + (size_t)first * 3;
@@ -675,8 +698,8 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
 RT_DEV void traceAnalytic(const DevScene& S, V3 o, V3 d, bool skipDebugSpheres, bool tracePlanes, bool skipDebugPlanes,
                           bool traceBoxes, Closest& best) {
     for (int i = 0; i < S.nSph; i++) {
-        f4_t g = ld4(S.sphGeom + i);
-        uint32_t flags = fbits(S.sphMat[3 * i + 2].w);
+        f4_t g = ldu4(S.sphGeom + i);
+        uint32_t flags = lduFlags(S.sphMat + 3 * i + 2);
         if (flags & 2u) continue;
         float t0;
         if (sphereHit(xyz(g), g.w, o, d, t0)) {
@@ -686,10 +709,10 @@ RT_DEV void traceAnalytic(const DevScene& S, V3 o, V3 d, bool skipDebugSpheres, 
     }
     if (tracePlanes) {
         for (int i = 0; i < S.nPln; i++) {
-            uint32_t flags = fbits(S.plnMat[3 * i + 2].w);
+            uint32_t flags = lduFlags(S.plnMat + 3 * i + 2);
             if (flags & 2u) continue;
             float t0;
-            if (planeHit(xyz(ld4(S.plnP + i)), xyz(ld4(S.plnN + i)), o, d, t0)) {
+            if (planeHit(xyz(ldu4(S.plnP + i)), xyz(ldu4(S.plnN + i)), o, d, t0)) {
                 if (skipDebugPlanes && (flags & 1u)) continue;
                 if (t0 < best.t) { best.t = t0; best.kind = KIND_PLANE; best.idx = i; }
             }
@@ -698,8 +721,8 @@ RT_DEV void traceAnalytic(const DevScene& S, V3 o, V3 d, bool skipDebugSpheres, 
     if (traceBoxes) {
         for (int i = 0; i < S.nBox; i++) {
             float t0;
-            if (boxHit(xyz(ld4(S.boxMin + i)), xyz(ld4(S.boxMax + i)), o, d, t0)) {
-                if (fbits(S.boxMat[3 * i + 2].w) & 1u) continue;   // boxes are always traced as reflection rays (kernels.cu:228)
+            if (boxHit(xyz(ldu4(S.boxMin + i)), xyz(ldu4(S.boxMax + i)), o, d, t0)) {
+                if (lduFlags(S.boxMat + 3 * i + 2) & 1u) continue;   // boxes are always traced as reflection rays (kernels.cu:228)
                 if (t0 < best.t) { best.t = t0; best.kind = KIND_BOX; best.idx = i; }
             }
         }
@@ -708,8 +731,8 @@ RT_DEV void traceAnalytic(const DevScene& S, V3 o, V3 d, bool skipDebugSpheres, 
 
 RT_DEV bool shadowSpheres(const DevScene& S, V3 o, V3 d) {
     for (int i = 0; i < S.nSph; i++) {
-        f4_t g = ld4(S.sphGeom + i);
-        uint32_t flags = fbits(S.sphMat[3 * i + 2].w);
+        f4_t g = ldu4(S.sphGeom + i);
+        uint32_t flags = lduFlags(S.sphMat + 3 * i + 2);
         if (flags & 2u) continue;
         float t0;
         if (sphereHit(xyz(g), g.w, o, d, t0) && !(flags & 1u)) return true;
@@ -720,7 +743,7 @@ RT_DEV bool shadowSpheres(const DevScene& S, V3 o, V3 d) {
 RT_DEV bool shadowBoxes(const DevScene& S, V3 o, V3 d) {
     for (int i = 0; i < S.nBox; i++) {
         float t0;
-        if (boxHit(xyz(ld4(S.boxMin + i)), xyz(ld4(S.boxMax + i)), o, d, t0) && !(fbits(S.boxMat[3 * i + 2].w) & 1u)) return true;
+        if (boxHit(xyz(ldu4(S.boxMin + i)), xyz(ldu4(S.boxMax + i)), o, d, t0) && !(lduFlags(S.boxMat + 3 * i + 2) & 1u)) return true;
     }
     return false;
 }
@@ -816,7 +839,10 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
     const bool modelsVisible = modelsRun && (P.flags & kCfgModelsVisible) != 0;
     const bool hardShadows = (P.flags & kCfgHardShadows) != 0, cull = (P.flags & kCfgCull) != 0;
     // 64 root entries must fit, and a full turn needs 88 free entries
-    const uint32_t nodeCapacity = (P.nodePoolEntries >= 96 && P.nodePoolEntries < kNodePool) ? (uint32_t)P.nodePoolEntries : (uint32_t)kNodePool;
+    // capacities of the two pools: the compiled ones unless the frame parameters ask for less (tests of the low-room paths)
+    const uint32_t askNodes = (uint32_t)P.nodePoolEntries & 0xffffu, askTris = (uint32_t)P.nodePoolEntries >> 16;
+    const uint32_t nodeCapacity = ((askNodes >= 96u && askNodes < (uint32_t)kNodePool) ? askNodes : (uint32_t)kNodePool)
+                                | (((askTris >= 72u && askTris < (uint32_t)kTriPool) ? askTris : (uint32_t)kTriPool) << 16);
 
     V3 lvl0 = background, lvl1 = background, lvl2 = background, lvl3 = background;
     float str0 = 0, str1 = 0, str2 = 0;

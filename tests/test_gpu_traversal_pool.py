@@ -1,7 +1,9 @@
 """The mesh traversal keeps the pending work of a wave's 64 rays in two LDS pools.  When the pool of pending children
-has fewer than 88 free entries, single lanes descend depth-first until there is room again.  The compiled capacity (512)
-is rarely exhausted, so these tests shrink it (RT_NODE_POOL, read when a context is created) until that path carries
-most of the traversal, and require byte-identical frames and oracle parity."""
+has fewer than 88 free entries, single lanes descend depth-first until there is room again; when the pool of triangle
+work (runs of triangles and sets of leaves) has fewer than 64 free entries, a triangle turn takes fewer entries and at
+the limit a single lane works on the newest one.  The compiled capacities (512 and 288) are rarely exhausted, so these
+tests shrink them (RT_NODE_POOL, RT_TRI_POOL, read when a context is created) until those paths carry most of the
+traversal, and require byte-identical frames and oracle parity."""
 import os
 
 import numpy as np
@@ -16,17 +18,18 @@ from cuda_ray_tracer_amd import binding, scenes  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=[96, 160])
+@pytest.fixture(params=[(96, 0), (160, 72), (0, 72), (0, 100)])
 def small_pool_renderer(request):
-    old = os.environ.get("RT_NODE_POOL")
-    os.environ["RT_NODE_POOL"] = str(request.param)
+    old = {k: os.environ.get(k) for k in ("RT_NODE_POOL", "RT_TRI_POOL")}
+    os.environ["RT_NODE_POOL"], os.environ["RT_TRI_POOL"] = str(request.param[0]), str(request.param[1])
     r = binding.Renderer(0)
     yield r
     r.close()
-    if old is None:
-        os.environ.pop("RT_NODE_POOL", None)
-    else:
-        os.environ["RT_NODE_POOL"] = old
+    for k, v in old.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 @pytest.mark.parametrize("mode", ["default", "eightboxes", "nobox", "deep"])
