@@ -446,6 +446,8 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
         ctx->nodeFloat4s = (int64_t)flat.nodes.size();
         ctx->triFloat4s = (int64_t)flat.tris.size();
     }
+    // the traversal keeps a node index in 29 bits of a pool entry (512 M nodes of 128 bytes would be 64 GB)
+    if (ctx->nodeFloat4s / rt::kNodeFloat4s >= ((int64_t)1 << 29)) { freeScene(ctx); return fail(RT_ERR_CAPACITY, "more than 2^29 octree nodes"); }
     ctx->mdlInfoHost = flat.mdlInfo;
     d.nSph = scene->sphereCount; d.nPln = scene->planeCount; d.nBox = scene->AABBCount; d.nMdl = scene->modelCount;
     d.forestRoot = flat.forestRoot;

@@ -45,6 +45,7 @@ constexpr uint32_t kSplitGainNum = 5, kSplitGainDen = 3;   // a block rendered b
 #endif
 constexpr int kNodePool = RT_NODE_POOL_ENTRIES;       // mesh traversal: entries of pending children per wave
 constexpr int kTriPool = 288;        // and of pending triangle work: runs of triangles, and sets of leaves of one node
+constexpr uint32_t kNodeIndexBits = 29, kNodeIndexMask = (1u << kNodeIndexBits) - 1u;   // node pool entry, low word: first child | octant << 29
 constexpr uint32_t kLeafSet = 1u << 27;   // triangle pool entry, high word: owner | chunks << 8 | (leaf set: hit mask << 16 | octant << 24 | kLeafSet)
 #ifndef RT_TRI_TURN_AT
 #define RT_TRI_TURN_AT 40u
@@ -237,7 +238,7 @@ struct WaveLds {
     f4_t* rayO; f4_t* rayD; f4_t* rayR;  // [64] ray of lane l: origin | gate bits low, direction | gate bits high, reciprocal direction | octant
     unsigned long long* bestKey;         // [64] ordered hit distance << 32 | triangle order key (see tracePool)
     uint32_t* bestRec;                   // [64] triangle record of the hit in bestKey
-    unsigned long long* nodePool;        // [kNodePool] pending children: node base | (imask | hits << 8 | owner << 16 | chunks << 24) << 32
+    unsigned long long* nodePool;        // [kNodePool] pending children: node base | ray octant << 29 | (imask | hits << 8 | owner << 16 | chunks << 24) << 32
     unsigned long long* triPool;         // [kTriPool] pending triangles: first record | (owner | chunks << 8) << 32, or a node's leaf set (kLeafSet)
     unsigned long long* prof;   // instrumented kernel only: 8 per-wave accumulators in LDS (see renderKernel)
 };
@@ -331,8 +332,7 @@ RT_DEV uint32_t testFour(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uin
 // worst-case error of this form (rt_scene.cpp) before rounding it outwards onto the node's grid: a plane's parameter
 // carries five roundings (subtraction, product, reciprocal 1 ulp, fma), each relative to the distance between the ray
 // origin and the node - under 3e-7 of that distance on the plane's axis, and a hit that counts is nearer than 999.
-RT_DEV uint32_t testChildren(const F4* node, u4_t head, const SlabRay& r, float tmin, float tmax) {
-    const u4_t qx = *reinterpret_cast<const u4_t*>(node + 2), qy = *reinterpret_cast<const u4_t*>(node + 3), qz = *reinterpret_cast<const u4_t*>(node + 4);
+RT_DEV uint32_t testChildren(u4_t head, u4_t qx, u4_t qy, u4_t qz, const SlabRay& r, float tmin, float tmax) {
     // plane at origin + q * step  ->  parameter (origin + q * step - o) / d = q * (step * rd) + (origin - o) * rd
     const V3 s = mk(ubits((head.w & 0xffu) << 23) * r.rd.x, ubits(((head.w >> 8) & 0xffu) << 23) * r.rd.y, ubits(((head.w >> 16) & 0xffu) << 23) * r.rd.z);
     const V3 b = mk((ubits(head.x) - r.o.x) * r.rd.x, (ubits(head.y) - r.o.y) * r.rd.y, (ubits(head.z) - r.o.z) * r.rd.z);
@@ -430,9 +430,9 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
     }
     const bool enters = hasRay && (!pregated || gateBits != 0);
     if (__ballot(enters) == 0ull) { timerWhole.stop(lds, 3); return false; }     // no ray of this wave comes near a mesh
+    const SlabRay own = makeSlabRay(o, d);
     {
         f4_t ro4 = {o.x, o.y, o.z, ubits((uint32_t)gateBits)}, rd4 = {d.x, d.y, d.z, ubits((uint32_t)(gateBits >> 32))};
-        const SlabRay own = makeSlabRay(o, d);
         f4_t rr4 = {own.rd.x, own.rd.y, own.rd.z, ubits(own.oct)};
         lds.rayO[lane] = ro4; lds.rayD[lane] = rd4;
         if (RT_RCP_IN_LDS) lds.rayR[lane] = rr4;
@@ -448,13 +448,13 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             const bool in = enters && ((gateBits >> j) & 1ull) != 0 && root != kNoRoot;
             const unsigned long long m = __ballot(in);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (in) lds.nodePool[nodeCount + rank] = (unsigned long long)root | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
+            if (in) lds.nodePool[nodeCount + rank] = (unsigned long long)(root | (own.oct << kNodeIndexBits)) | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
             nodeCount += (uint32_t)__builtin_popcountll(m);
         }
     } else {
         const unsigned long long m = __ballot(enters);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (enters) lds.nodePool[rank] = (unsigned long long)S.forestRoot | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
+        if (enters) lds.nodePool[rank] = (unsigned long long)(S.forestRoot | (own.oct << kNodeIndexBits)) | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
         nodeCount = (uint32_t)__builtin_popcountll(m);
     }
     __builtin_amdgcn_wave_barrier();
@@ -473,9 +473,19 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             unsigned long long e = 0;
             if (mine) e = lds.nodePool[nodeCount - 1u - lane];
             nodeCount -= take;
-            const uint32_t base = (uint32_t)e, packed = (uint32_t)(e >> 32);
+            // the low word names the children and the ray's octant, so the record of the nearest hit child can be requested
+            // before the ray itself has arrived from LDS
+            const uint32_t low = (uint32_t)e, packed = (uint32_t)(e >> 32);
+            const uint32_t base = low & kNodeIndexMask, oct = low >> kNodeIndexBits;
             const uint32_t imask = packed & 0xffu, hits = (packed >> 8) & 0xffu, owner = (packed >> 16) & 63u;
             uint32_t chunkMask = packed >> 24;
+            const uint32_t visited = base + __builtin_popcount(imask & ((1u << ((uint32_t)__builtin_ctz(hits | 0x100u) ^ oct)) - 1u));
+            const F4* np = S.nodes + (size_t)visited * kNodeFloat4s;
+            u4_t head, meta, qx, qy, qz;      // read by the lanes that loaded them
+            if (mine) {
+                head = *reinterpret_cast<const u4_t*>(np); meta = *reinterpret_cast<const u4_t*>(np + 1);
+                qx = *reinterpret_cast<const u4_t*>(np + 2); qy = *reinterpret_cast<const u4_t*>(np + 3); qz = *reinterpret_cast<const u4_t*>(np + 4);
+            }
             unsigned long long bk = 0;
             if (mine) bk = lds.bestKey[owner];
             const bool alive = mine && !(ANYHIT && bk == 0ull);
@@ -485,12 +495,12 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 const bool again = alive && rest != 0u;
                 const unsigned long long m = __ballot(again);
                 const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-                if (again) lds.nodePool[nodeCount + rank] = (unsigned long long)base | ((unsigned long long)(imask | (rest << 8) | (owner << 16) | (chunkMask << 24)) << 32);
+                if (again) lds.nodePool[nodeCount + rank] = (unsigned long long)low | ((unsigned long long)(imask | (rest << 8) | (owner << 16) | (chunkMask << 24)) << 32);
                 nodeCount += (uint32_t)__builtin_popcountll(m);
             }
-            // childBase, childImask, oct and visited are read only where childHits or pend is not zero - where a lane has set
-            // them below (no start values: they would be written by every lane every turn)
-            uint32_t childHits = 0, pend = 0, childBase, childImask, oct, visited;
+            // childBase and childImask are read only where childHits is not zero - where a lane has set them below (no start
+            // values: they would be written by every lane every turn)
+            uint32_t childHits = 0, pend = 0, childBase, childImask;
             if (alive) {
                 const f4_t ro4 = lds.rayO[owner];
                 const V3 ro = xyz(ro4);
@@ -498,19 +508,13 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 f4_t rdHere = {0, 0, 0, 0};
                 if (RT_RCP_IN_LDS) {
                     const f4_t rr4 = lds.rayR[owner];
-                    sr.rd = xyz(rr4); sr.o = ro; sr.oct = fbits(rr4.w);
+                    sr.rd = xyz(rr4); sr.o = ro; sr.oct = oct;
                 } else {
                     rdHere = lds.rayD[owner];
                     sr = makeSlabRay(ro, xyz(rdHere));
                 }
-                oct = sr.oct;
-                const uint32_t c = (uint32_t)__builtin_ctz(hits) ^ oct;
-                const uint32_t node = base + __builtin_popcount(imask & ((1u << c) - 1u));
-                visited = node;
-                const F4* np = S.nodes + (size_t)node * kNodeFloat4s;
-                const u4_t head = *reinterpret_cast<const u4_t*>(np), meta = *reinterpret_cast<const u4_t*>(np + 1);
                 const float tmax = ANYHIT ? FAR_T : orderFloat((uint32_t)(bk >> 32));
-                uint32_t hmask = testChildren(np, head, sr, tmin, tmax);
+                uint32_t hmask = testChildren(head, qx, qy, qz, sr, tmin, tmax);
                 if (meta.z != kNoModel) {       // root of a model's octree: the model's gates decide whether the ray enters it
                     const int mm = (int)meta.z;
                     const f4_t rd4 = RT_RCP_IN_LDS ? lds.rayD[owner] : rdHere;
@@ -530,7 +534,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                 }
                 const uint32_t nodeImask = meta.y & 0xffu, nodeLmask = (meta.y >> 8) & 0xffu;
                 if (STATS) { cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask); cnt.nodeVisits++; }
-                childBase = meta.x; childImask = nodeImask;
+                childBase = meta.x | (oct << kNodeIndexBits); childImask = nodeImask;
                 // meta.y holds the internal mask in byte 0 and the leaf mask in byte 1: both are permuted at once
                 const uint32_t both = permuteOctants((hmask | (hmask << 8)) & meta.y & 0xffffu, oct);
                 childHits = both & 0xffu;
@@ -612,9 +616,9 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             }
             bool goesOn = false;
             if (alive) {
+                const V3 ro = xyz(lds.rayO[owner]), rdir = xyz(lds.rayD[owner]);
                 const F4* tp = S.tris + (size_t)first * 3;
                 const f4_t A0 = ld4(tp), B0 = ld4(tp + 1), C0 = ld4(tp + 2), A1 = ld4(tp + 3), B1 = ld4(tp + 4), C1 = ld4(tp + 5);
-                const V3 ro = xyz(lds.rayO[owner]), rdir = xyz(lds.rayD[owner]);
                 auto testTriangle = [&](f4_t A, f4_t B, f4_t C, uint32_t record) {
                     const uint32_t idw = fbits(A.w);
                     if (STATS) cnt.triTests++;
