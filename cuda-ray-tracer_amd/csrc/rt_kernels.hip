@@ -32,8 +32,7 @@ typedef uint32_t u4_t __attribute__((ext_vector_type(4)));
 constexpr int kBlockThreads = 64;   // render workgroups are single waves
 constexpr uint32_t kSplitGainNum = 5, kSplitGainDen = 3;   // a block rendered by eight split waves is taken to finish 5/3 times sooner (measured: 1.65)
 // Occupancy of the render kernel: four waves per SIMD (128 registers; what does not fit is spilled around the traces, not
-// inside them) with 10 KB of LDS per wave - measured 5 % faster than three waves with 168 registers and 12.4 KB, although the
-// node pool is smaller and the reciprocal direction is recomputed per entry instead of kept in LDS.
+// inside them) with 10 KB of LDS per wave - measured 5 % faster than three waves with 168 registers and 12.4 KB.
 #ifndef RT_WAVES_PER_SIMD
 #define RT_WAVES_PER_SIMD 4
 #endif
@@ -47,8 +46,10 @@ constexpr int kNodePool = RT_NODE_POOL_ENTRIES;       // mesh traversal: entries
 constexpr int kTriPool = 288;        // and of pending triangle work: runs of triangles, and sets of leaves of one node
 constexpr uint32_t kNodeIndexBits = 29, kNodeIndexMask = (1u << kNodeIndexBits) - 1u;   // node pool entry, low word: first child | octant << 29
 constexpr uint32_t kLeafSet = 1u << 27;   // triangle pool entry, high word: owner | chunks << 8 | (leaf set: hit mask << 16 | octant << 24 | kLeafSet)
+// Triangle turns are taken once this many entries are pending (1080p benchmark frame: 24 -> +8 %, 40 -> +2 %, 52 .. 58 within
+// 0.5 % of each other, 64 -> +1 %, 96 -> +4 %).
 #ifndef RT_TRI_TURN_AT
-#define RT_TRI_TURN_AT 40u
+#define RT_TRI_TURN_AT 56u
 #endif
 constexpr int kDirectStartModels = 6;  // up to this many models a trace can start at the model roots (one pool entry per ray and model)
 constexpr int kExactRankTiles = 4096;  // up to this many tiles are ranked by all-pairs comparison
@@ -386,8 +387,9 @@ RT_DEV float orderFloat(uint32_t m) { return ubits((m & 0x80000000u) ? (m & 0x7f
 // Pool capacity: a lane's node turn takes one entry and adds at most two (remaining siblings, new children), so a full
 // turn needs 64 free entries; with fewer than 88 free, only as many lanes take entries as leaves 24 in reserve, and at
 // the limit single lanes take turns (depth-first on the newest entry, which needs at most one more entry per tree
-// level) until there is room again.  A node turn adds at most eight triangle runs per
-// lane, and is only taken with fewer than 40 runs pending.
+// level) until there is room again.  A node turn adds at most one entry per lane to the pool of triangle work (the set
+// of leaves the ray hit in the node) and is only taken while that pool has room for 64 and holds fewer than RT_TRI_TURN_AT
+// entries; the triangle turns take the leaves off a set one by one, nearest first.
 template <bool ANYHIT, bool STATS>
 RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t poolCapacity, uint32_t trav, Closest& best, WaveLds lds, Counters& cnt) {
     if (S.forestRoot == kNoRoot) return false;
@@ -1065,8 +1067,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
     const uint32_t lead = extraWaves ? ((uint32_t)P.leadWaves < regularWaves ? (uint32_t)P.leadWaves : regularWaves) : 0u;
     const bool splitWave = blockIndex >= lead && blockIndex < lead + extraWaves;
     const uint32_t waveIndex = blockIndex < lead ? blockIndex : blockIndex - (splitWave ? lead : extraWaves);    // among the waves of its kind
-    // 12416 bytes per wave: twelve waves per CU (three per SIMD) fit the 160 KB of LDS.  Measured: at 12928 bytes fewer
-    // waves are resident and the frame takes 7 % longer.
+    // 10240 bytes per wave: sixteen waves per CU (four per SIMD) fit the 160 KB of LDS exactly.
     __shared__ f4_t poolRays[(RT_RCP_IN_LDS ? 3 : 2) * kBlockThreads];
     __shared__ unsigned long long poolBest[kBlockThreads];
     __shared__ uint32_t poolRec[kBlockThreads];
