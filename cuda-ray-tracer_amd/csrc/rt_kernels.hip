@@ -60,6 +60,21 @@ struct V3 { float x, y, z; };
 
 RT_DEV V3 mk(float x, float y, float z) { V3 r; r.x = x; r.y = y; r.z = z; return r; }
 RT_DEV V3 mk(const float* p) { return mk(p[0], p[1], p[2]); }
+// Values that are the same for the whole launch and lie in the kernel-argument segment (or, for a camera path, in a table in
+// global memory that nothing writes while the kernel runs) are read where they are used, through the constant address space:
+// scalar loads served by the scalar cache.  Loaded once at kernel entry instead, the hundred-odd words would have to live in
+// scalar registers for the whole kernel - there are 102 - and most of them would be moved into spare vector-register lanes
+// and back (one vector instruction each way).
+// The accesses are volatile ones: each read in the source is one scalar load at that place - the compiler neither moves it to
+// the top of the kernel (from where the value would have to be kept) nor merges it with another read, so code that needs a
+// value several times reads it into a local variable first.
+#define RT_KARG __attribute__((address_space(4)))
+typedef const volatile RT_KARG FrameParams FrameK;
+typedef const volatile RT_KARG DevScene SceneK;
+typedef const volatile RT_KARG float* CamK;      // 16 floats: position, up, right, direction, fovFactor, view vector (FrameParams::camPos .. eyeDir)
+RT_DEV V3 mk(const volatile RT_KARG float* p) { return mk(p[0], p[1], p[2]); }
+// A pointer read from the argument segment is a generic one; through this cast the accesses become global ones.
+template <typename T> RT_DEV T* inGlobal(T* p) { return (T*)(__attribute__((address_space(1))) T*)p; }
 RT_DEV V3 xyz(f4_t v) { return mk(v.x, v.y, v.z); }
 RT_DEV V3 operator+(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
 RT_DEV V3 operator-(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
@@ -391,8 +406,9 @@ RT_DEV float orderFloat(uint32_t m) { return ubits((m & 0x80000000u) ? (m & 0x7f
 // of leaves the ray hit in the node) and is only taken while that pool has room for 64 and holds fewer than RT_TRI_TURN_AT
 // entries; the triangle turns take the leaves off a set one by one, nearest first.
 template <bool ANYHIT, bool STATS>
-RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t poolCapacity, uint32_t trav, Closest& best, WaveLds lds, Counters& cnt) {
-    if (S.forestRoot == kNoRoot) return false;
+RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t poolCapacity, uint32_t trav, Closest& best, WaveLds lds, Counters& cnt) {
+    const uint32_t forestRoot = S.forestRoot;
+    if (forestRoot == kNoRoot) return false;
     const uint32_t nodeCapacity = poolCapacity & 0xffffu, triCapacity = poolCapacity >> 16;
     SectionTimer<STATS> timerWhole;
     const uint32_t lane = threadIdx.x & 63u;
@@ -404,11 +420,11 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
     // Is model mm a candidate for the ray at all: not hidden from this ray type, and (whole-box mode) through the
     // reference's exact bounding-box gate.
     // (uniform: mm is the same for the whole wave)
-    auto gate = [&](int mm, V3 ro, V3 rdir, V3 rrd, bool fin, const bool uniform) -> bool {
-        if ((skipDebug || ANYHIT) && ((uniform ? lduFlags(S.mdlMat + 3 * mm + 2) : fbits(S.mdlMat[3 * mm + 2].w)) & 1u)) return false;
+    auto gate = [&](const F4* mdlMat, const F4* gateMin, const F4* gateMax, int mm, V3 ro, V3 rdir, V3 rrd, bool fin, const bool uniform) -> bool {
+        if ((skipDebug || ANYHIT) && ((uniform ? lduFlags(mdlMat + 3 * mm + 2) : fbits(mdlMat[3 * mm + 2].w)) & 1u)) return false;
         if (meshMode == kMeshWholeBox) {
             if (STATS) cnt.gateTests++;
-            const f4_t lo = uniform ? ldu4(S.mdlGateMin + mm) : ld4(S.mdlGateMin + mm), hi = uniform ? ldu4(S.mdlGateMax + mm) : ld4(S.mdlGateMax + mm);
+            const f4_t lo = uniform ? ldu4(gateMin + mm) : ld4(gateMin + mm), hi = uniform ? ldu4(gateMax + mm) : ld4(gateMax + mm);
             return boxHitDecision(xyz(lo), xyz(hi), ro, rdir, rrd, fin);
         }
         return true;
@@ -424,9 +440,11 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
         SectionTimer<STATS> timerG;
         const SlabRay sr = makeSlabRay(o, d);
         const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
+        const F4* const tightMin = inGlobal(S.mdlTightMin), * const tightMax = inGlobal(S.mdlTightMax);
+        const F4* const mdlMat = inGlobal(S.mdlMat), * const gateMin = inGlobal(S.mdlGateMin), * const gateMax = inGlobal(S.mdlGateMax);
         for (int j = 0; j < nMdl; j++) {
-            if (!tightBoxHit(xyz(ldu4(S.mdlTightMin + j)), xyz(ldu4(S.mdlTightMax + j)), sr, tmin, startT)) continue;
-            if (gate(j, o, d, sr.rd, fin, true)) gateBits |= 1ull << j;
+            if (!tightBoxHit(xyz(ldu4(tightMin + j)), xyz(ldu4(tightMax + j)), sr, tmin, startT)) continue;
+            if (gate(mdlMat, gateMin, gateMax, j, o, d, sr.rd, fin, true)) gateBits |= 1ull << j;
         }
         timerG.stop(lds, 2);
     }
@@ -440,13 +458,16 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
         if (RT_RCP_IN_LDS) lds.rayR[lane] = rr4;
         lds.bestKey[lane] = init;
     }
+    // what the turns below read through, for the whole loop in scalar registers
+    const F4* const nodes = inGlobal(S.nodes), * const tris = inGlobal(S.tris);
+    const uint32_t* const mdlInfo = inGlobal(S.mdlInfo);
     // one pseudo entry per ray that resolves to the forest root
     uint32_t nodeCount, triCount = 0;
     if ((trav & kTravDirectStart) && pregated && nMdl <= kDirectStartModels && (uint32_t)nMdl * 64u + 88u <= nodeCapacity) {
         // few models, gates known: one entry per ray and model whose gate the ray passed, resolving to that model's root
         nodeCount = 0;
         for (int j = 0; j < nMdl; j++) {
-            const uint32_t root = lduw(S.mdlInfo + 4 * j);
+            const uint32_t root = lduw(mdlInfo + 4 * j);
             const bool in = enters && ((gateBits >> j) & 1ull) != 0 && root != kNoRoot;
             const unsigned long long m = __ballot(in);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -456,7 +477,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
     } else {
         const unsigned long long m = __ballot(enters);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (enters) lds.nodePool[rank] = (unsigned long long)(S.forestRoot | (own.oct << kNodeIndexBits)) | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
+        if (enters) lds.nodePool[rank] = (unsigned long long)(forestRoot | (own.oct << kNodeIndexBits)) | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
         nodeCount = (uint32_t)__builtin_popcountll(m);
     }
     __builtin_amdgcn_wave_barrier();
@@ -482,7 +503,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             const uint32_t imask = packed & 0xffu, hits = (packed >> 8) & 0xffu, owner = (packed >> 16) & 63u;
             uint32_t chunkMask = packed >> 24;
             const uint32_t visited = base + __builtin_popcount(imask & ((1u << ((uint32_t)__builtin_ctz(hits | 0x100u) ^ oct)) - 1u));
-            const F4* np = S.nodes + (size_t)visited * kNodeFloat4s;
+            const F4* np = nodes + (size_t)visited * kNodeFloat4s;
             u4_t head, meta, qx, qy, qz;      // read by the lanes that loaded them
             if (mine) {
                 head = *reinterpret_cast<const u4_t*>(np); meta = *reinterpret_cast<const u4_t*>(np + 1);
@@ -523,12 +544,13 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                     const V3 rdir = xyz(rd4);
                     const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
                     const unsigned long long bits = (unsigned long long)fbits(ro4.w) | ((unsigned long long)fbits(rd4.w) << 32);
-                    bool enter = pregated ? (((bits >> mm) & 1ull) != 0) : gate(mm, ro, rdir, sr.rd, fin, false);
+                    bool enter = pregated ? (((bits >> mm) & 1ull) != 0) : gate(inGlobal(S.mdlMat), inGlobal(S.mdlGateMin), inGlobal(S.mdlGateMax), mm, ro, rdir, sr.rd, fin, false);
                     if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
                         chunkMask = 0;
+                        const F4* const chunkMin = inGlobal(S.mdlChunkMin), * const chunkMax = inGlobal(S.mdlChunkMax);
                         for (int b = 0; b < 8; b++) {
                             if (STATS) cnt.gateTests++;
-                            if (boxHitDecision(xyz(ld4(S.mdlChunkMin + 8 * mm + b)), xyz(ld4(S.mdlChunkMax + 8 * mm + b)), ro, rdir, sr.rd, fin)) chunkMask |= 1u << b;
+                            if (boxHitDecision(xyz(ld4(chunkMin + 8 * mm + b)), xyz(ld4(chunkMax + 8 * mm + b)), ro, rdir, sr.rd, fin)) chunkMask |= 1u << b;
                         }
                         enter = chunkMask != 0;
                     }
@@ -606,7 +628,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             if (alive && (hi & kLeafSet)) {
                 const uint32_t mask = (hi >> 16) & 0xffu;
                 const uint32_t lc = (uint32_t)__builtin_ctz(mask) ^ ((hi >> 24) & 7u);
-                first = reinterpret_cast<const uint32_t*>(S.nodes + (size_t)lo * kNodeFloat4s + 5)[lc];
+                first = reinterpret_cast<const uint32_t*>(nodes + (size_t)lo * kNodeFloat4s + 5)[lc];
                 restMask = mask & (mask - 1u);
             }
             {
@@ -619,7 +641,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
             bool goesOn = false;
             if (alive) {
                 const V3 ro = xyz(lds.rayO[owner]), rdir = xyz(lds.rayD[owner]);
-                const F4* tp = S.tris + (size_t)first * 3;
+                const F4* tp = tris + (size_t)first * 3;
                 const f4_t A0 = ld4(tp), B0 = ld4(tp + 1), C0 = ld4(tp + 2), A1 = ld4(tp + 3), B1 = ld4(tp + 4), C1 = ld4(tp + 5);
                 auto testTriangle = [&](f4_t A, f4_t B, f4_t C, uint32_t record) {
                     const uint32_t idw = fbits(A.w);
@@ -646,7 +668,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
                         return;
                     }
                     const int mm = (int)fbits(B.w);
-                    const uint32_t key = S.mdlInfo[4 * mm + 1] + (idw & kTriIdMask);
+                    const uint32_t key = mdlInfo[4 * mm + 1] + (idw & kTriIdMask);
                     const unsigned long long cand = ((unsigned long long)orderBits(t + 0.0f) << 32) | key;    // -0 orders as +0
                     if (cand < bk) {
                         atomicMin(&lds.bestKey[owner], cand);
@@ -678,7 +700,7 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
         } else if (bk != init) {
             // the winning triangle once more, for t, u and v
             const uint32_t record = lds.bestRec[lane];
-            const F4* tp = S.tris + (size_t)record * 3;
+            const F4* tp = tris + (size_t)record * 3;
             const f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
             V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
             V3 pvec = cross(d, e2);
@@ -701,11 +723,13 @@ RT_DEV bool tracePool(const DevScene& S, bool hasRay, V3 o, V3 d, bool cull, boo
 
 // kernels.cu:67-96 over the three analytic object tables, closest hit.  skipDebug* mirror the ray types the
 // reference uses for each table at this level.
-RT_DEV void traceAnalytic(const DevScene& S, V3 o, V3 d, bool skipDebugSpheres, bool tracePlanes, bool skipDebugPlanes,
+RT_DEV void traceAnalytic(SceneK& S, V3 o, V3 d, bool skipDebugSpheres, bool tracePlanes, bool skipDebugPlanes,
                           bool traceBoxes, Closest& best) {
-    for (int i = 0; i < S.nSph; i++) {
-        f4_t g = ldu4(S.sphGeom + i);
-        uint32_t flags = lduFlags(S.sphMat + 3 * i + 2);
+    const int nSph = S.nSph;
+    const F4* const sphGeom = inGlobal(S.sphGeom), * const sphMat = inGlobal(S.sphMat);
+    for (int i = 0; i < nSph; i++) {
+        f4_t g = ldu4(sphGeom + i);
+        uint32_t flags = lduFlags(sphMat + 3 * i + 2);
         if (flags & 2u) continue;
         float t0;
         if (sphereHit(xyz(g), g.w, o, d, t0)) {
@@ -714,31 +738,37 @@ RT_DEV void traceAnalytic(const DevScene& S, V3 o, V3 d, bool skipDebugSpheres, 
         }
     }
     if (tracePlanes) {
-        for (int i = 0; i < S.nPln; i++) {
-            uint32_t flags = lduFlags(S.plnMat + 3 * i + 2);
+        const int nPln = S.nPln;
+        const F4* const plnP = inGlobal(S.plnP), * const plnN = inGlobal(S.plnN), * const plnMat = inGlobal(S.plnMat);
+        for (int i = 0; i < nPln; i++) {
+            uint32_t flags = lduFlags(plnMat + 3 * i + 2);
             if (flags & 2u) continue;
             float t0;
-            if (planeHit(xyz(ldu4(S.plnP + i)), xyz(ldu4(S.plnN + i)), o, d, t0)) {
+            if (planeHit(xyz(ldu4(plnP + i)), xyz(ldu4(plnN + i)), o, d, t0)) {
                 if (skipDebugPlanes && (flags & 1u)) continue;
                 if (t0 < best.t) { best.t = t0; best.kind = KIND_PLANE; best.idx = i; }
             }
         }
     }
     if (traceBoxes) {
-        for (int i = 0; i < S.nBox; i++) {
+        const int nBox = S.nBox;
+        const F4* const boxMin = inGlobal(S.boxMin), * const boxMax = inGlobal(S.boxMax), * const boxMat = inGlobal(S.boxMat);
+        for (int i = 0; i < nBox; i++) {
             float t0;
-            if (boxHit(xyz(ldu4(S.boxMin + i)), xyz(ldu4(S.boxMax + i)), o, d, t0)) {
-                if (lduFlags(S.boxMat + 3 * i + 2) & 1u) continue;   // boxes are always traced as reflection rays (kernels.cu:228)
+            if (boxHit(xyz(ldu4(boxMin + i)), xyz(ldu4(boxMax + i)), o, d, t0)) {
+                if (lduFlags(boxMat + 3 * i + 2) & 1u) continue;   // boxes are always traced as reflection rays (kernels.cu:228)
                 if (t0 < best.t) { best.t = t0; best.kind = KIND_BOX; best.idx = i; }
             }
         }
     }
 }
 
-RT_DEV bool shadowSpheres(const DevScene& S, V3 o, V3 d) {
-    for (int i = 0; i < S.nSph; i++) {
-        f4_t g = ldu4(S.sphGeom + i);
-        uint32_t flags = lduFlags(S.sphMat + 3 * i + 2);
+RT_DEV bool shadowSpheres(SceneK& S, V3 o, V3 d) {
+    const int nSph = S.nSph;
+    const F4* const sphGeom = inGlobal(S.sphGeom), * const sphMat = inGlobal(S.sphMat);
+    for (int i = 0; i < nSph; i++) {
+        f4_t g = ldu4(sphGeom + i);
+        uint32_t flags = lduFlags(sphMat + 3 * i + 2);
         if (flags & 2u) continue;
         float t0;
         if (sphereHit(xyz(g), g.w, o, d, t0) && !(flags & 1u)) return true;
@@ -746,10 +776,13 @@ RT_DEV bool shadowSpheres(const DevScene& S, V3 o, V3 d) {
     return false;
 }
 
-RT_DEV bool shadowBoxes(const DevScene& S, V3 o, V3 d) {
-    for (int i = 0; i < S.nBox; i++) {
+RT_DEV bool shadowBoxes(SceneK& S, V3 o, V3 d) {
+    const int nBox = S.nBox;
+    if (nBox == 0) return false;
+    const F4* const boxMin = inGlobal(S.boxMin), * const boxMax = inGlobal(S.boxMax), * const boxMat = inGlobal(S.boxMat);
+    for (int i = 0; i < nBox; i++) {
         float t0;
-        if (boxHit(xyz(ldu4(S.boxMin + i)), xyz(ldu4(S.boxMax + i)), o, d, t0) && !(lduFlags(S.boxMat + 3 * i + 2) & 1u)) return true;
+        if (boxHit(xyz(ldu4(boxMin + i)), xyz(ldu4(boxMax + i)), o, d, t0) && !(lduFlags(boxMat + 3 * i + 2) & 1u)) return true;
     }
     return false;
 }
@@ -758,18 +791,21 @@ RT_DEV bool shadowBoxes(const DevScene& S, V3 o, V3 d) {
 
 // v = normalise(cameraPosition) (kernels.cu:20-65 evaluates it per pixel; it is the same for the whole frame and arrives in
 // the frame parameters, computed on the host with the same three divisions and square root).
-RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 v, V3 normal, const FrameParams& P, int px, int py) {
+RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 v, V3 normal, FrameK& P, int px, int py) {
     V3 colour = mk(0, 0, 0);
     V3 L = normalise(lightPos - point);
-    if (P.flags & kCfgAmbient) colour = (lightCol * mat.ka) * mat.ambient;
-    if (P.flags & kCfgDiffuse) {
+    const uint32_t flags = P.flags;
+    if (flags & kCfgAmbient) colour = (lightCol * mat.ka) * mat.ambient;
+    if (flags & kCfgDiffuse) {
         float NdotL = selMax(dot(normal, L), 0.0f);
         colour = colour + ((NdotL > 0.0f) ? (((mat.kd * lightCol) * mat.diffuse) * NdotL) : mk(0, 0, 0));
     }
-    if (P.flags & kCfgSpecular) {
-        if (P.flags & kCfgAreaSpecular) {
-            for (int i = 0; i < P.softNum; i++) {
-                V3 ps = lightSampleOffset(sampleSeed(px, py, i), P.softRadius);
+    if (flags & kCfgSpecular) {
+        if (flags & kCfgAreaSpecular) {
+            const int softNum = P.softNum;
+            const float softRadius = P.softRadius;
+            for (int i = 0; i < softNum; i++) {
+                V3 ps = lightSampleOffset(sampleSeed(px, py, i), softRadius);
                 V3 Ls = normalise((lightPos + ps) - point);
                 V3 r = normalise(neg(reflect(Ls, normal)));
                 float RdotV = selMax(dot(r, v), 0.0f);
@@ -794,22 +830,22 @@ struct Surface {
 // the winning object's own routine to the last one: each of them normalises the stored normal once more
 // (kernels.cu:90-93, 122-125).
 template <bool STATS>
-RT_DEV Surface resolveSurface(const DevScene& S, V3 o, V3 d, const Closest& h, int renorm, Counters& cnt) {
+RT_DEV Surface resolveSurface(SceneK& S, V3 o, V3 d, const Closest& h, int renorm, Counters& cnt) {
     Surface s;
     s.point = o + d * h.t;
     if (h.kind == KIND_SPHERE) {
-        s.mat = loadMat(S.sphMat, h.idx);
-        s.normal = s.point - xyz(ld4(S.sphGeom + h.idx));
+        s.mat = loadMat(inGlobal(S.sphMat), h.idx);
+        s.normal = s.point - xyz(ld4(inGlobal(S.sphGeom) + h.idx));
     } else if (h.kind == KIND_PLANE) {
-        s.mat = loadMat(S.plnMat, h.idx);
-        s.normal = neg(xyz(ld4(S.plnN + h.idx)));
+        s.mat = loadMat(inGlobal(S.plnMat), h.idx);
+        s.normal = neg(xyz(ld4(inGlobal(S.plnN) + h.idx)));
     } else if (h.kind == KIND_BOX) {
-        s.mat = loadMat(S.boxMat, h.idx);
-        s.normal = boxNormalAt(xyz(ld4(S.boxMin + h.idx)), xyz(ld4(S.boxMax + h.idx)), s.point);
+        s.mat = loadMat(inGlobal(S.boxMat), h.idx);
+        s.normal = boxNormalAt(xyz(ld4(inGlobal(S.boxMin) + h.idx)), xyz(ld4(inGlobal(S.boxMax) + h.idx)), s.point);
     } else {
-        s.mat = loadMat(S.mdlMat, h.idx);
-        uint32_t triBase = S.mdlInfo[4 * h.idx + 1];
-        const F4* ap = S.attrs + (size_t)(triBase + (uint32_t)h.tri) * kAttrFloat4s;
+        s.mat = loadMat(inGlobal(S.mdlMat), h.idx);
+        uint32_t triBase = inGlobal(S.mdlInfo)[4 * h.idx + 1];
+        const F4* ap = inGlobal(S.attrs) + (size_t)(triBase + (uint32_t)h.tri) * kAttrFloat4s;
         f4_t a0 = ld4(ap), a1 = ld4(ap + 1), a2 = ld4(ap + 2), a3 = ld4(ap + 3), a4 = ld4(ap + 4), a5 = ld4(ap + 5), a6 = ld4(ap + 6);
         if (STATS) cnt.attrFetches++;
         float u = h.u, v = h.v, w = 1 - u - v;
@@ -838,18 +874,8 @@ RT_DEV int renormCount(int kind, bool planesRun, bool boxesRun, bool modelsRun) 
 // and a lane without a ray at that point - outside the frame, chain ended, nothing to shade - passes hasRay = false and
 // lends its lane to the others.  `live`: the lane has a camera sample at all.
 template <bool STATS>
-RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V3 d, int px, int py, WaveLds lds, Counters& cnt, Closest& primaryOut) {
-    const V3 lightPos = mk(S.lightPos), lightCol = mk(S.lightCol), eye = mk(P.eyeDir), background = mk(P.background);
-    const bool reflections = (P.flags & kCfgReflections) != 0, reflectPlanes = (P.flags & kCfgReflectPlanes) != 0;
-    const bool boxesRun = (P.flags & kCfgRenderBoxes) != 0, modelsRun = (P.flags & kCfgRenderModels) != 0;
-    const bool modelsVisible = modelsRun && (P.flags & kCfgModelsVisible) != 0;
-    const bool hardShadows = (P.flags & kCfgHardShadows) != 0, cull = (P.flags & kCfgCull) != 0;
-    // 64 root entries must fit, and a full turn needs 88 free entries
-    // capacities of the two pools: the compiled ones unless the frame parameters ask for less (tests of the low-room paths)
-    const uint32_t askNodes = (uint32_t)P.nodePoolEntries & 0xffffu, askTris = (uint32_t)P.nodePoolEntries >> 16;
-    const uint32_t nodeCapacity = ((askNodes >= 96u && askNodes < (uint32_t)kNodePool) ? askNodes : (uint32_t)kNodePool)
-                                | (((askTris >= 72u && askTris < (uint32_t)kTriPool) ? askTris : (uint32_t)kTriPool) << 16);
-
+RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int px, int py, WaveLds lds, Counters& cnt, Closest& primaryOut) {
+    const V3 background = mk(P.background);
     V3 lvl0 = background, lvl1 = background, lvl2 = background, lvl3 = background;
     float str0 = 0, str1 = 0, str2 = 0;
     bool add0 = false, add1 = false, add2 = false, sh0 = false, sh1 = false, sh2 = false, sh3 = false;
@@ -861,6 +887,16 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
 #pragma unroll 1
     for (int level = 0; level < 4; level++) {
         if (__ballot(active) == 0ull) break;
+        // the settings are read once per level, so that nothing of them has to be kept across levels
+        const uint32_t flags = P.flags;
+        const bool reflections = (flags & kCfgReflections) != 0, reflectPlanes = (flags & kCfgReflectPlanes) != 0;
+        const bool boxesRun = (flags & kCfgRenderBoxes) != 0, modelsRun = (flags & kCfgRenderModels) != 0;
+        const bool modelsVisible = modelsRun && (flags & kCfgModelsVisible) != 0;
+        const bool hardShadows = (flags & kCfgHardShadows) != 0, cull = (flags & kCfgCull) != 0;
+        // capacities of the two pools: the compiled ones unless the frame parameters ask for less (tests of the low-room paths)
+        const uint32_t askPools = (uint32_t)P.nodePoolEntries, askNodes = askPools & 0xffffu, askTris = askPools >> 16;
+        const uint32_t nodeCapacity = ((askNodes >= 96u && askNodes < (uint32_t)kNodePool) ? askNodes : (uint32_t)kNodePool)
+                                    | (((askTris >= 72u && askTris < (uint32_t)kTriPool) ? askTris : (uint32_t)kTriPool) << 16);
         Closest h; h.t = FAR_T; h.kind = KIND_NONE; h.idx = -1; h.tri = -1; h.u = 0; h.v = 0;
         const bool planesRun = (level == 0) || reflectPlanes;
         if (active) {
@@ -883,7 +919,8 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
                 colour = s.mat.ka;                                          // kernels.cu:309-312
             } else {
                 V3 nLight = (level == 0 && h.kind == KIND_BOX) ? s.normal : normalise(s.normal);   // kernels.cu:240-245
-                colour = lighting(s.mat, lightPos, lightCol, s.point, eye, nLight, P, px, py);
+                const V3 lightPos = mk(S.lightPos);
+                colour = lighting(s.mat, lightPos, mk(S.lightCol), s.point, mk(cam + 13), nLight, P, px, py);
                 lit = true;
                 point = s.point; normal = s.normal;
                 biased = s.point + s.normal * P.shadowBias;
@@ -903,8 +940,9 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
             // shadow rays of the primary hit: the hard shadow ray (kernels.cu:268-277, stops at the first occluder kind), then
             // the soft shadow samples (kernels.cu:279-307, every occluder kind counts separately)
             const int hardRays = hardShadows ? 1 : 0;
-            const bool soft = (P.flags & kCfgSoftShadows) != 0;
-            const int shadowRays = hardRays + (soft ? P.softNum : 0);
+            const bool soft = (flags & kCfgSoftShadows) != 0;
+            const int softNum = soft ? P.softNum : 0;
+            const int shadowRays = hardRays + softNum;
             int hitsCount = 0;
 #pragma unroll 1
             for (int q = 0; q < shadowRays; q++) {
@@ -915,7 +953,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
                 if (lit) {
                     if (!hard) {
                         V3 ps = lightSampleOffset(sampleSeed(px, py, q - hardRays), P.softRadius);
-                        V3 lightPoint = lightPos + ps;
+                        V3 lightPoint = mk(S.lightPos) + ps;
                         sd = normalise(lightPoint - point);
                     }
                     cnt.rays++;
@@ -925,7 +963,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
                     tmSh.stop(lds, 6);
                 }
                 bool byModel = false;
-                if (P.flags & kCfgModelsVisible) {   // the shadow traces ignore renderModels (kernels.cu:304)
+                if (flags & kCfgModelsVisible) {   // the shadow traces ignore renderModels (kernels.cu:304)
                     const bool needModel = lit && !(hard && (bySphere || byBox));
                     Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
                     byModel = tracePool<true, STATS>(S, needModel, biased, sd, cull, true, P.meshMode, nodeCapacity, (uint32_t)P.traversal, dummy, lds, cnt);
@@ -936,7 +974,7 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
                 }
             }
             if (soft && lit) {
-                softFactor = 1 - ((float)hitsCount / (float)P.softNum);
+                softFactor = 1 - ((float)hitsCount / (float)softNum);
                 useSoft = true;
             }
         } else if (hardShadows && lit) {
@@ -960,17 +998,18 @@ RT_DEV V3 castSample(const DevScene& S, const FrameParams& P, bool live, V3 o, V
     }
 
     // fold the levels back together in the reference's order of operations
+    const float shadowIntensity = P.shadowIntensity;
     V3 c3 = lvl3;
-    if (sh3) c3 = c3 * P.shadowIntensity;                               // kernels.cu:140-144
+    if (sh3) c3 = c3 * shadowIntensity;                               // kernels.cu:140-144
     V3 c2 = lvl2;
-    if (sh2) c2 = c2 * P.shadowIntensity;                               // kernels.cu:162-166 (before the add)
+    if (sh2) c2 = c2 * shadowIntensity;                               // kernels.cu:162-166 (before the add)
     if (deepest >= 3 && add2) c2 = c2 + c3 * str2;                      // kernels.cu:168-180
     V3 c1 = lvl1;
     if (deepest >= 2 && add1) c1 = c1 + c2 * str1;                      // kernels.cu:198-210
-    if (sh1) c1 = c1 * P.shadowIntensity;                               // kernels.cu:212-216 (after the add)
+    if (sh1) c1 = c1 * shadowIntensity;                               // kernels.cu:212-216 (after the add)
     V3 c0 = lvl0;
     if (deepest >= 1 && add0) c0 = c0 + c1 * str0;                      // kernels.cu:248-266
-    if (sh0) c0 = c0 * P.shadowIntensity;                               // kernels.cu:268-277
+    if (sh0) c0 = c0 * shadowIntensity;                               // kernels.cu:268-277
     if (useSoft) c0 = c0 * softFactor;                                  // kernels.cu:306
     return c0;
 }
@@ -997,11 +1036,12 @@ RT_DEV void separateScalars(T& v) {
     for (int i = 0; i < words; i++) { uint32_t q; asm volatile("s_mov_b32 %0, %1" : "=s"(q) : "s"(w[i])); w[i] = q; }
 }
 
-RT_DEV V3 rasterToCameraSpace(const FrameParams& P, float x, float y) {
+RT_DEV V3 rasterToCameraSpace(FrameK& P, CamK cam, float x, float y) {
     float ndcx = x / (float)P.width, ndcy = y / (float)P.height;
     float sx = 2 * ndcx - 1, sy = 1 - 2 * ndcy;
-    float cx = sx * 1 * P.fovFactor, cy = sy * P.fovFactor, cz = 1;
-    return (mk(P.camRight) * cx + mk(P.camUp) * cy) + mk(P.camDir) * cz;
+    const float fovFactor = cam[12];
+    float cx = sx * 1 * fovFactor, cy = sy * fovFactor, cz = 1;
+    return (mk(cam + 6) * cx + mk(cam + 3) * cy) + mk(cam + 9) * cz;
 }
 
 RT_DEV uint8_t packChannel(float c) {
@@ -1022,7 +1062,8 @@ RT_DEV uint32_t evenBits3(uint32_t v) { return (v & 1u) | ((v >> 1) & 2u) | ((v 
 // waves, the ones listed in fb.extraMap, each rendering one pixel row of one of the frame's heaviest blocks: eight lanes
 // bring a pixel, the other 56 only help with the mesh traversal.
 // Waves one frame's launch consists of (the regular waves; split waves come on top).
-__host__ __device__ inline uint32_t wavesPerFrame(const FrameParams& P) {
+template <typename Frame>
+__host__ __device__ inline uint32_t wavesPerFrame(const Frame& P) {
     const int tilesLaunched = P.blockOrder == 2 ? ((P.ownedTiles + 7) / 8) * 8 : P.ownedTiles;
     return (uint32_t)(tilesLaunched * kWavesPerTile);
 }
@@ -1031,30 +1072,38 @@ __host__ __device__ inline uint32_t wavesPerFrame(const FrameParams& P) {
 // render frame f with the camera pathCams[f] (16 floats: position, up, right, direction, fovFactor, view vector - the layout
 // of FrameParams::camPos .. eyeDir) into out + f * pathFrameBytes.  Frames follow each other in dispatch order, so the first
 // waves of frame f + 1 fill the GPU while the slow tail of frame f drains.  Nothing is split in this mode.
+// The parameter list of renderKernel as it lies in the kernel-argument segment (every parameter at the next offset that
+// its alignment allows, which is how a struct with the same members is laid out).
+struct RenderArgs {
+    DevScene scene; FrameParams frame; uint8_t* out; int32_t* ids; float* tbuf; unsigned long long* counters;
+    unsigned long long* waveClocks; const uint32_t* tileOrder; uint32_t* tileCost; BlockFeedback fb;
+    const float* pathCams; unsigned long long pathFrameBytes;
+};
+// Nothing is taken from the parameters themselves: everything is read from the argument segment where it is used (see RT_KARG).
 template <bool STATS, bool PATH = false>
-__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_SIMD))) void renderKernel(DevScene sceneArg, FrameParams frameArg, uint8_t* __restrict__ out, int32_t* __restrict__ ids,
-                                                    float* __restrict__ tbuf, unsigned long long* __restrict__ counters,
-                                                    unsigned long long* __restrict__ waveClocks, const uint32_t* __restrict__ tileOrder,
-                                                    uint32_t* __restrict__ tileCost, BlockFeedback fb,
-                                                    const float* __restrict__ pathCams, unsigned long long pathFrameBytes) {
-    // The argument structs arrive through 16-dword scalar loads, and a value that lives in such a register tuple is spilled
-    // and brought back sixteen lanes at a time: every field becomes a scalar value of its own here.
-    DevScene S = sceneArg; FrameParams P = frameArg;
-    uint32_t blockIndex = blockIdx.x, gridBlocks = gridDim.x;
+__global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_SIMD))) void renderKernel(DevScene, FrameParams, uint8_t*, int32_t*, float*, unsigned long long*,
+                                                    unsigned long long*, const uint32_t*, uint32_t*, BlockFeedback, const float*, unsigned long long) {
+    // (the address passes through an empty asm statement: a pointer known to be the argument segment is known to be readable
+    // everywhere, and every load from it would be moved to the top of the kernel - the very thing this is meant to avoid)
+    unsigned long long argSegment = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(argSegment));
+    const RT_KARG RenderArgs& A = *(const RT_KARG RenderArgs*)argSegment;
+    FrameK& P = A.frame;
+    SceneK& S = A.scene;
+    uint32_t blockIndex = blockIdx.x, gridBlocks = gridDim.x, frameIndex = 0;
+    CamK cam = &P.camPos[0];
     if (PATH) {
         const uint32_t perFrame = wavesPerFrame(P);
-        const uint32_t frameIndex = blockIndex / perFrame;
+        frameIndex = blockIndex / perFrame;
         blockIndex -= frameIndex * perFrame; gridBlocks = perFrame;
-        const float* cam = pathCams + 16u * frameIndex;       // wave-uniform: scalar loads
-        for (int k = 0; k < 3; k++) { P.camPos[k] = cam[k]; P.camUp[k] = cam[3 + k]; P.camRight[k] = cam[6 + k]; P.camDir[k] = cam[9 + k]; P.eyeDir[k] = cam[13 + k]; }
-        P.fovFactor = cam[12];
-        out += (size_t)frameIndex * pathFrameBytes;
+        cam = (CamK)(unsigned long long)(A.pathCams + 16u * frameIndex);       // wave-uniform: scalar loads
     }
-    separateScalars<19>(S); separateScalars<0>(P);
     const unsigned long long clockStart = STATS ? __builtin_amdgcn_s_memrealtime() : 0ull;   // 100 MHz wall clock
-    const unsigned long long costStart = tileCost ? __builtin_amdgcn_s_memrealtime() : 0ull;    // costs are wall time in 10 ns units
-    if (fb.hint && blockIndex == 0 && threadIdx.x == 0) *fb.hint = *fb.extraCount;   // tells the host whether splitting is on
-    if (fb.frameStart && blockIndex == 0 && threadIdx.x == 0) *fb.frameStart = costStart;
+    const unsigned long long costStart = __builtin_amdgcn_s_memrealtime();    // costs are wall time in 10 ns units
+    if (blockIndex == 0 && threadIdx.x == 0) {
+        if (A.fb.hint) *A.fb.hint = *A.fb.extraCount;   // tells the host whether splitting is on
+        if (A.fb.frameStart) *A.fb.frameStart = costStart;
+    }
     // Grid order with splitting: the regular waves of the heaviest unsplit tiles (the first P.leadWaves waves in tile order,
     // nearly as long as the split blocks), then the split waves, then the other regular waves; workgroups are dispatched in
     // index order.  Share of 1/2, 1/4, 1/8 of the 1080p benchmark frame, one frame in flight: 0.244 / 0.228 / 0.168 ms with
@@ -1084,9 +1133,9 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
     uint32_t localTile, inTile, sub = 0;
     bool retire = false;
     if (splitWave) {
-        const uint32_t count = *fb.extraCount;
+        const uint32_t count = *inGlobal(A.fb.extraCount);
         if (waveIndex < (count < (uint32_t)kMaxExtraWaves ? count : (uint32_t)kMaxExtraWaves)) {
-            const uint32_t e = fb.extraMap[waveIndex];
+            const uint32_t e = inGlobal(A.fb.extraMap)[waveIndex];
             const uint32_t blk = e & 0xFFFFFu;
             sub = (e >> 20) & 7u;
             localTile = blk / (uint32_t)kWavesPerTile; inTile = blk % (uint32_t)kWavesPerTile;
@@ -1104,22 +1153,22 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
         }
         // Expensive tiles first: the slowest waves of a frame run several hundred times longer than the median, so they
         // must not be the last to start.  tileOrder lists this rank's tiles by the cost measured on the previous frame.
-        if (!retire && tileOrder) {
-            localTile = tileOrder[localTile];
+        if (!retire && A.tileOrder) {
+            localTile = inGlobal(A.tileOrder)[localTile];
             // an order list is a permutation of the rank's tiles; should a caller ever hand over one that is not (two launches
             // racing on a shared list), the wave gives up instead of rendering outside the frame
             if (localTile >= (uint32_t)P.ownedTiles) retire = true;
         }
-        if (!retire && P.split && *fb.extraCount != 0u) {
+        if (!retire && P.split && *inGlobal(A.fb.extraCount) != 0u) {
             const uint32_t blk = localTile * (uint32_t)kWavesPerTile + inTile;
-            if ((fb.heavyBits[blk >> 5] >> (blk & 31u)) & 1u) retire = true;      // split waves render this block
+            if ((inGlobal(A.fb.heavyBits)[blk >> 5] >> (blk & 31u)) & 1u) retire = true;      // split waves render this block
         }
     }
     // diagnostic records: the regular waves first, then the split waves
     const size_t recordIndex = splitWave ? (size_t)regularWaves + waveIndex : (size_t)waveIndex;
     if (retire) {
-        if (STATS && waveClocks && lane == 0) {
-            for (int k = 0; k < kWaveRecordWords; k++) waveClocks[kWaveRecordWords * recordIndex + k] = 0;
+        if (STATS && A.waveClocks && lane == 0) {
+            for (int k = 0; k < kWaveRecordWords; k++) A.waveClocks[kWaveRecordWords * recordIndex + k] = 0;
         }
         return;
     }
@@ -1135,7 +1184,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
     Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; cnt.nodeVisits = 0;
     const bool inFrame = pixelLane && x < P.width && y < P.height;
     {      // all 64 lanes, also those without a pixel: the mesh trace is a wave-wide operation
-        const V3 camPos = mk(P.camPos);
+        const V3 camPos = mk(cam);
         V3 col;
         Closest primary; primary.t = FAR_T; primary.kind = KIND_NONE; primary.idx = -1; primary.tri = -1; primary.u = 0; primary.v = 0;
         // One loop over the camera samples so that the whole ray pipeline is instantiated once: the centre of the pixel
@@ -1147,9 +1196,9 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
 #pragma unroll 1
         for (int sIdx = 0; sIdx < samples; sIdx++) {
             const float offX = antiAlias ? ((sIdx & 2) ? 0.75f : 0.25f) : 0.5f, offY = antiAlias ? ((sIdx & 1) ? 0.75f : 0.25f) : 0.5f;
-            V3 p = rasterToCameraSpace(P, (float)x + offX, (float)y + offY);
+            V3 p = rasterToCameraSpace(P, cam, (float)x + offX, (float)y + offY);
             Closest ph;
-            V3 c = castSample<STATS>(S, P, inFrame, camPos, normalise(p), x, y, lds, cnt, ph);
+            V3 c = castSample<STATS>(S, P, cam, inFrame, camPos, normalise(p), x, y, lds, cnt, ph);
             if (sIdx == 0) primary = ph;
             total = antiAlias ? total + c : c;
         }
@@ -1158,6 +1207,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
             size_t pix;
             if (P.compactOutput) pix = (size_t)localTile * (RT_TILE_PX * RT_TILE_PX) + (size_t)ly * RT_TILE_PX + lx;
             else pix = (size_t)y * (size_t)P.width + (size_t)x;
+            uint8_t* out = inGlobal(A.out);
+            if (PATH) out += (size_t)frameIndex * A.pathFrameBytes;
+            int32_t* ids = inGlobal(A.ids);
+            float* tbuf = inGlobal(A.tbuf);
             out[pix * 3 + 0] = packChannel(col.x);
             out[pix * 3 + 1] = packChannel(col.y);
             out[pix * 3 + 2] = packChannel(col.z);
@@ -1172,12 +1225,13 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
             }
         }
     }
-    if (STATS && waveClocks && lane == 0) {      // diagnostic: when this wave started and finished, and its section sums
-        unsigned long long* rec = waveClocks + kWaveRecordWords * recordIndex;
+    if (STATS && A.waveClocks && lane == 0) {      // diagnostic: when this wave started and finished, and its section sums
+        unsigned long long* rec = A.waveClocks + kWaveRecordWords * recordIndex;
         rec[0] = clockStart;
         rec[1] = __builtin_amdgcn_s_memrealtime();
         for (int k = 0; k < 16; k++) rec[2 + k] = lds.prof[k];
     }
+    uint32_t* tileCost = inGlobal(A.tileCost);
     if (tileCost && lane == 0) {
         const unsigned long long spent = __builtin_amdgcn_s_memrealtime() - costStart;
         // a split wave stands for the whole block: count it as what one regular wave would have needed.  The factor is a
@@ -1186,9 +1240,11 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
         const uint32_t own = (uint32_t)spent + 1u;
         const uint32_t cost = splitWave ? own * 3u / 2u : own;
         atomicMax(&tileCost[localTile], cost);   // a tile is as urgent as its slowest wave
-        if (fb.blockCost) atomicMax(&fb.blockCost[localTile * (uint32_t)kWavesPerTile + inTile], cost);
+        uint32_t* blockCost = inGlobal(A.fb.blockCost);
+        if (blockCost) atomicMax(&blockCost[localTile * (uint32_t)kWavesPerTile + inTile], cost);
     }
     // one atomic per wave and counter
+    unsigned long long* counters = inGlobal(A.counters);
     if (counters) {
         uint32_t vals[kCntCount] = {cnt.rays, cnt.nodeTests, cnt.triTests, cnt.attrFetches, cnt.gateTests, cnt.nodeVisits};
 #pragma unroll
