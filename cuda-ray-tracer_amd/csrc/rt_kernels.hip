@@ -878,8 +878,10 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
     const V3 background = mk(P.background);
     V3 lvl0 = background, lvl1 = background, lvl2 = background, lvl3 = background;
     float str0 = 0, str1 = 0, str2 = 0;
-    bool add0 = false, add1 = false, add2 = false, sh0 = false, sh1 = false, sh2 = false, sh3 = false;
-    float softFactor = 1.0f; bool useSoft = false;
+    // per-lane flags of the levels in one register (as booleans each would be a lane mask in a pair of scalar registers, kept
+    // across every trace of the sample): bit l = level l is shadowed, bit 4 + l = level l + 1 is added to level l, bit 8 = soft
+    uint32_t levelBits = 0;
+    float softFactor = 1.0f;
     int deepest = 0;
 
     bool active = live;
@@ -975,17 +977,15 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
             }
             if (soft && lit) {
                 softFactor = 1 - ((float)hitsCount / (float)softNum);
-                useSoft = true;
+                levelBits |= 256u;
             }
         } else if (hardShadows && lit) {
             cnt.rays++;
             shadowed = shadowSpheres(S, biased, toLight);                                  // kernels.cu:142, 164, 214
         }
         if (lit) {
-            if (level == 0) { str0 = strength; add0 = add; sh0 = shadowed; }
-            else if (level == 1) { str1 = strength; add1 = add; sh1 = shadowed; }
-            else if (level == 2) { str2 = strength; add2 = add; sh2 = shadowed; }
-            else { sh3 = shadowed; }
+            if (level == 0) str0 = strength; else if (level == 1) str1 = strength; else if (level == 2) str2 = strength;
+            levelBits |= ((shadowed ? 1u : 0u) | (add ? 16u : 0u)) << level;
             if (wantNext) {
                 next = true;
                 V3 r = normalise(reflect(rdir, normal));
@@ -1000,17 +1000,17 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
     // fold the levels back together in the reference's order of operations
     const float shadowIntensity = P.shadowIntensity;
     V3 c3 = lvl3;
-    if (sh3) c3 = c3 * shadowIntensity;                               // kernels.cu:140-144
+    if (levelBits & 8u) c3 = c3 * shadowIntensity;                               // kernels.cu:140-144
     V3 c2 = lvl2;
-    if (sh2) c2 = c2 * shadowIntensity;                               // kernels.cu:162-166 (before the add)
-    if (deepest >= 3 && add2) c2 = c2 + c3 * str2;                      // kernels.cu:168-180
+    if (levelBits & 4u) c2 = c2 * shadowIntensity;                               // kernels.cu:162-166 (before the add)
+    if (deepest >= 3 && (levelBits & 64u)) c2 = c2 + c3 * str2;                      // kernels.cu:168-180
     V3 c1 = lvl1;
-    if (deepest >= 2 && add1) c1 = c1 + c2 * str1;                      // kernels.cu:198-210
-    if (sh1) c1 = c1 * shadowIntensity;                               // kernels.cu:212-216 (after the add)
+    if (deepest >= 2 && (levelBits & 32u)) c1 = c1 + c2 * str1;                      // kernels.cu:198-210
+    if (levelBits & 2u) c1 = c1 * shadowIntensity;                               // kernels.cu:212-216 (after the add)
     V3 c0 = lvl0;
-    if (deepest >= 1 && add0) c0 = c0 + c1 * str0;                      // kernels.cu:248-266
-    if (sh0) c0 = c0 * shadowIntensity;                               // kernels.cu:268-277
-    if (useSoft) c0 = c0 * softFactor;                                  // kernels.cu:306
+    if (deepest >= 1 && (levelBits & 16u)) c0 = c0 + c1 * str0;                      // kernels.cu:248-266
+    if (levelBits & 1u) c0 = c0 * shadowIntensity;                               // kernels.cu:268-277
+    if (levelBits & 256u) c0 = c0 * softFactor;                                  // kernels.cu:306
     return c0;
 }
 
