@@ -483,6 +483,9 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
     __builtin_amdgcn_wave_barrier();
 
     while (nodeCount != 0 || triCount != 0) {
+        // (the two counts are the same in every lane; said explicitly, because otherwise the arithmetic on them ends up in
+        // vector instructions)
+        nodeCount = (uint32_t)__builtin_amdgcn_readfirstlane((int)nodeCount); triCount = (uint32_t)__builtin_amdgcn_readfirstlane((int)triCount);
         // a node turn adds at most one triangle entry per lane
         const bool nodeTurn = nodeCount != 0 && triCount < RT_TRI_TURN_AT && triCount + 65u <= triCapacity;
         if (nodeTurn) {
