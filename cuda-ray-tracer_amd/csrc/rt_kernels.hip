@@ -1018,27 +1018,6 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
 }
 
 
-// Copies every field of a kernel-argument struct into a scalar register of its own (an explicit move, which the register
-// coalescer cannot fold back into the loaded tuple): the first `pointers` fields as 64-bit values, the rest as 32-bit values.
-template <int pointers, typename T>
-RT_DEV void separateScalars(T& v) {
-    static_assert(sizeof(T) % 4 == 0 && sizeof(T) >= 8 * (size_t)pointers, "struct of pointers followed by 32-bit fields");
-    constexpr int words = (int)((sizeof(T) - 8 * (size_t)pointers) / 4);
-    typedef const __attribute__((address_space(1))) char* GlobalPtr;
-    // The pointers come back from the asm statement as integers; converting them to pointers into global memory (and from
-    // there to the generic pointers the struct holds) keeps the loads through them global loads instead of flat ones.
-    const char** ptrs = reinterpret_cast<const char**>(&v);
-#pragma unroll
-    for (int i = 0; i < pointers; i++) {
-        unsigned long long in = reinterpret_cast<unsigned long long>(ptrs[i]), q;
-        asm volatile("s_mov_b64 %0, %1" : "=s"(q) : "s"(in));
-        ptrs[i] = (const char*)(GlobalPtr)q;
-    }
-    uint32_t* w = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(&v) + 8 * (size_t)pointers);
-#pragma unroll
-    for (int i = 0; i < words; i++) { uint32_t q; asm volatile("s_mov_b32 %0, %1" : "=s"(q) : "s"(w[i])); w[i] = q; }
-}
-
 RT_DEV V3 rasterToCameraSpace(FrameK& P, CamK cam, float x, float y) {
     float ndcx = x / (float)P.width, ndcy = y / (float)P.height;
     float sx = 2 * ndcx - 1, sy = 1 - 2 * ndcy;
