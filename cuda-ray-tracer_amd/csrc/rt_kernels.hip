@@ -876,7 +876,7 @@ RT_DEV int renormCount(int kind, bool planesRun, bool boxesRun, bool modelsRun) 
 // ray, then up to three reflections).  Every mesh trace sits in wave-uniform control flow: all 64 lanes call tracePool,
 // and a lane without a ray at that point - outside the frame, chain ended, nothing to shade - passes hasRay = false and
 // lends its lane to the others.  `live`: the lane has a camera sample at all.
-template <bool STATS>
+template <bool STATS, bool IDS>
 RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int px, int py, WaveLds lds, Counters& cnt, Closest& primaryOut) {
     const V3 background = mk(P.background);
     V3 lvl0 = background, lvl1 = background, lvl2 = background, lvl3 = background;
@@ -911,7 +911,7 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
         }
         // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
         if (modelsVisible) tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, nodeCapacity, (uint32_t)P.traversal, h, lds, cnt);
-        if (level == 0 && active) primaryOut = h;
+        if (IDS && level == 0 && active) primaryOut = h;
         V3 colour = background;
         bool next = false, lit = false, wantNext = false, add = false, shadowed = false;
         float strength = 0;
@@ -1062,7 +1062,9 @@ struct RenderArgs {
     const float* pathCams; unsigned long long pathFrameBytes;
 };
 // Nothing is taken from the parameters themselves: everything is read from the argument segment where it is used (see RT_KARG).
-template <bool STATS, bool PATH = false>
+// IDS: the launch also writes the primary hit's ids and / or distance per pixel; without, the six registers of that hit need not
+// be kept from the first trace of a pixel to its last.
+template <bool STATS, bool PATH = false, bool IDS = true>
 __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(RT_WAVES_PER_SIMD))) void renderKernel(DevScene, FrameParams, uint8_t*, int32_t*, float*, unsigned long long*,
                                                     unsigned long long*, const uint32_t*, uint32_t*, BlockFeedback, const float*, unsigned long long) {
     // (the address passes through an empty asm statement: a pointer known to be the argument segment is known to be readable
@@ -1180,8 +1182,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
             const float offX = antiAlias ? ((sIdx & 2) ? 0.75f : 0.25f) : 0.5f, offY = antiAlias ? ((sIdx & 1) ? 0.75f : 0.25f) : 0.5f;
             V3 p = rasterToCameraSpace(P, cam, (float)x + offX, (float)y + offY);
             Closest ph;
-            V3 c = castSample<STATS>(S, P, cam, inFrame, camPos, normalise(p), x, y, lds, cnt, ph);
-            if (sIdx == 0) primary = ph;
+            V3 c = castSample<STATS, IDS>(S, P, cam, inFrame, camPos, normalise(p), x, y, lds, cnt, ph);
+            if (IDS && sIdx == 0) primary = ph;
             total = antiAlias ? total + c : c;
         }
         col = antiAlias ? total / 4.0f : total;
@@ -1191,8 +1193,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
             else pix = (size_t)y * (size_t)P.width + (size_t)x;
             uint8_t* out = inGlobal(A.out);
             if (PATH) out += (size_t)frameIndex * A.pathFrameBytes;
-            int32_t* ids = inGlobal(A.ids);
-            float* tbuf = inGlobal(A.tbuf);
+            int32_t* ids = IDS ? inGlobal(A.ids) : nullptr;
+            float* tbuf = IDS ? inGlobal(A.tbuf) : nullptr;
             out[pix * 3 + 0] = packChannel(col.x);
             out[pix * 3 + 1] = packChannel(col.y);
             out[pix * 3 + 2] = packChannel(col.z);
@@ -1312,7 +1314,8 @@ hipError_t launchRender(const DevScene& S, const FrameParams& P, uint8_t* out, i
     if (P.ownedTiles <= 0) return hipSuccess;
     dim3 grid(launchGridBlocks(P) + (P.split ? (unsigned)kMaxExtraWaves : 0u)), block(kBlockThreads);
     if (stats) hipLaunchKernelGGL((renderKernel<true>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb, nullptr, 0ull);
-    else hipLaunchKernelGGL((renderKernel<false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb, nullptr, 0ull);
+    else if (ids || tbuf) hipLaunchKernelGGL((renderKernel<false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb, nullptr, 0ull);
+    else hipLaunchKernelGGL((renderKernel<false, false, false>), grid, block, 0, stream, S, P, out, ids, tbuf, counters, waveClocks, tileOrder, tileCost, fb, nullptr, 0ull);
     return hipGetLastError();
 }
 
@@ -1322,7 +1325,7 @@ hipError_t launchRenderPath(const DevScene& S, const FrameParams& P, uint8_t* ou
     const unsigned long long blocks = (unsigned long long)launchGridBlocks(P) * (unsigned long long)frames;
     if (blocks > 0x7fffffffull) return hipErrorInvalidValue;
     const BlockFeedback none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipLaunchKernelGGL((renderKernel<false, true>), dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, S, P, out, (int32_t*)nullptr, (float*)nullptr,
+    hipLaunchKernelGGL((renderKernel<false, true, false>), dim3((unsigned)blocks), dim3(kBlockThreads), 0, stream, S, P, out, (int32_t*)nullptr, (float*)nullptr,
                        (unsigned long long*)nullptr, (unsigned long long*)nullptr, tileOrder, tileCost, none, dPathCams, (unsigned long long)frameBytes);
     return hipGetLastError();
 }
