@@ -27,6 +27,10 @@ for seed in range(first, first + count):
     built = scenes.build_scene(spec, build_on_device=bool(seed % 3 == 2))
     r.upload(built.desc); r.set_state(built.camera, cfg)
     g_rgb, g_ids, g_t, st = r.render_ids(w, h)
+    plain, st_plain = r.render(w, h)          # the kernel variant without id / distance outputs must paint the same frame
+    if not np.array_equal(plain, g_rgb) or st_plain.rays != st.rays:
+        bad += 1
+        print("VARIANT MISMATCH seed", seed, int((plain != g_rgb).any(axis=-1).sum()), "pixels", flush=True)
     o_rgb, o_ids, o_t, o_rays, _ = O.render(built.desc, built.camera, cfg, w, h, threads=16)
     s = compare_frames(g_rgb, g_ids, g_t, o_rgb, o_ids, o_t, None)
     total_px += s["pixels"]; lsb += s["px_gt0"]; mesh_px += int((g_ids[..., 0] >> 24 == 4).sum())
