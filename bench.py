@@ -205,6 +205,7 @@ def main():
         torch.cuda.set_stream(torch.cuda.Stream(device=dev))
         stream = torch.cuda.current_stream().cuda_stream
     lanes = [(r, torch.cuda.current_stream(), frame)]
+    last_frame = [frame]       # where the newest complete frame is
     for _ in range(lane_count - 1):
         extra = binding.Renderer(device_index)
         extra.upload(built.desc)
@@ -234,6 +235,7 @@ def main():
         # The exchange (gather, reassembly on rank 0) runs on a stream of its own, so that the render streams go from
         # frame to frame without waiting: they only wait before overwriting a slot whose gather has not finished.
         xs = torch.cuda.Stream(device=dev) if os.environ.get("RT_BENCH_XSTREAM", "1") == "1" else torch.cuda.current_stream()
+        batch_frames = torch.empty(batch * pixels * 3, dtype=torch.uint8, device=dev) if rank == 0 else None     # the reassembled frames of one batch
         rendered_ev = [[torch.cuda.Event() for _ in range(batch)] for _ in range(slots)]
         free_ev = [None] * slots
 
@@ -247,8 +249,11 @@ def main():
                     free_ev[slot] = torch.cuda.Event()
                 free_ev[slot].record(xs)
                 if rank == 0:
-                    for j in range(frames):      # rank q's buffer of the slot's j-th frame starts at q * slot_bytes + j * tile_bytes
-                        r.untile_strided_device(w, h, share, gathered[slot].data_ptr() + j * tile_bytes, slot_bytes, frame.data_ptr(), xs.cuda_stream)
+                    # rank q's buffer of the slot's j-th frame starts at q * slot_bytes + j * tile_bytes; the frames of the batch
+                    # are reassembled by one launch (beside render launches that fill the GPU, a reassembly kernel mostly waits
+                    # for registers to come free - once per launch)
+                    r.untile_batch_device(w, h, share, gathered[slot].data_ptr(), slot_bytes, tile_bytes, frames, batch_frames.data_ptr(), xs.cuda_stream)
+                    last_frame[0] = batch_frames.narrow(0, (frames - 1) * pixels * 3, pixels * 3)
 
     # Several GPUs: a rank's share of a frame is short, and issuing it costs the host as much as rendering it costs the GPU.
     # With frames gathered in batches anyway, the whole batch goes out as one launch (rt_render_path_tiles_device).
@@ -387,7 +392,7 @@ def main():
                  if kernel_events else elapsed * 1e3 / args.steps)
     by_flight = {str(in_flight): elapsed * 1e3 / args.steps}
     # What the timed frames look like: the last one, as rank 0 holds it (copied now, before any other leg renders again).
-    timed_frame = frame.cpu().numpy().reshape(h, w, 3).copy() if rank == 0 else None
+    timed_frame = last_frame[0].cpu().numpy().reshape(h, w, 3).copy() if rank == 0 else None
     if second_leg:
         flight[0] = other_flight
         steps2 = max(1, min(args.steps, 200))

@@ -49,6 +49,7 @@ def lib():
     L.rt_render_tiles_device.argtypes = [vp, i32, i32, i32, i32, vp, sz, vp]
     L.rt_untile_device.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     L.rt_untile_strided_device.argtypes = [vp, i32, i32, i32, vp, sz, vp, vp]
+    L.rt_untile_batch_device.argtypes = [vp, i32, i32, i32, vp, sz, sz, i32, vp, vp]
     L.rt_count_rays.argtypes = [vp, i32, i32, C.POINTER(T.FrameStats)]
     L.rt_get_scene_info.argtypes = [vp, C.POINTER(T.SceneInfo)]
     L.rt_profile_waves.argtypes = [vp, i32, i32, vp, sz, C.POINTER(sz)]
@@ -155,6 +156,10 @@ class Renderer:
     def untile_strided_device(self, width, height, world, d_gathered_ptr, rank_stride_bytes, d_rgb_ptr, stream=None):
         _check(lib().rt_untile_strided_device(self._ctx, width, height, world, C.c_void_p(d_gathered_ptr), rank_stride_bytes,
                                               C.c_void_p(d_rgb_ptr), C.c_void_p(stream or 0)))
+
+    def untile_batch_device(self, width, height, world, d_gathered_ptr, rank_stride_bytes, frame_stride_bytes, n_frames, d_rgb_frames_ptr, stream=None):
+        _check(lib().rt_untile_batch_device(self._ctx, width, height, world, C.c_void_p(d_gathered_ptr), rank_stride_bytes, frame_stride_bytes,
+                                            n_frames, C.c_void_p(d_rgb_frames_ptr), C.c_void_p(stream or 0)))
 
     def profile_waves(self, width, height):
         """Per-wave diagnostic records of one instrumented frame: uint64 array [waves, 18] (see rt_profile_waves)."""

@@ -97,8 +97,13 @@ struct rt_ctx {
     volatile uint32_t* hSplitWaves = nullptr;
     uint32_t* dSplitWaves = nullptr;
     float* dPathCams = nullptr;          // RT_MAX_PATH_FRAMES x 16 floats: the cameras of a camera-path launch
-    float* hPathCams = nullptr;          // pinned staging copy of the same (the asynchronous copy reads it after the call returns)
-    hipEvent_t pathCamsFree = nullptr;   // recorded after the copy out of hPathCams: the next path call waits for it before refilling
+    // Pinned staging copies of the same, used in turn (the asynchronous copy reads one after the call has returned, and it runs
+    // only when the launch before it on that stream is done: with a single staging buffer every path call would wait for the
+    // previous launch to finish).  pathCamsFree[i] is recorded after the copy out of slot i; a call waits for its slot's event.
+    static constexpr int kPathStaging = 4;
+    float* hPathCams = nullptr;
+    hipEvent_t pathCamsFree[kPathStaging] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned pathCalls = 0;
     rt::StaticScratch* staticScratch = nullptr;   // this device's record of the never-allocated scratch (rt_render_device_static)
     bool strictOctreeFlag = false;   // config.octree hides meshes, as the reference's unfinished branch does
     bool forceDeviceBuild = false;   // RT_DEVICE_BUILD=1: build every scene's octrees on the GPU
@@ -364,8 +369,9 @@ int rt_create(int device_count, const int* devices, rt_ctx** out) {
     if (e == hipSuccess) { e = hipMalloc(&q, sizeof(rt::SplitState)); if (e == hipSuccess) { c->dSplitState = static_cast<rt::SplitState*>(q); e = hipMemset(q, 0, sizeof(rt::SplitState)); } }
     if (e != hipSuccess) { rt_destroy(c); return failHip(e, "hipMalloc(tile order)"); }
     e = hipMalloc(&q, sizeof(float) * 16 * RT_MAX_PATH_FRAMES);
-    if (e == hipSuccess) { c->dPathCams = static_cast<float*>(q); e = hipHostMalloc(&q, sizeof(float) * 16 * RT_MAX_PATH_FRAMES, hipHostMallocDefault); }
-    if (e == hipSuccess) { c->hPathCams = static_cast<float*>(q); e = hipEventCreateWithFlags(&c->pathCamsFree, hipEventDisableTiming); }
+    if (e == hipSuccess) { c->dPathCams = static_cast<float*>(q); e = hipHostMalloc(&q, sizeof(float) * 16 * RT_MAX_PATH_FRAMES * rt_ctx::kPathStaging, hipHostMallocDefault); }
+    if (e == hipSuccess) c->hPathCams = static_cast<float*>(q);
+    for (int i = 0; i < rt_ctx::kPathStaging && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->pathCamsFree[i], hipEventDisableTiming);
     if (e != hipSuccess) { rt_destroy(c); return failHip(e, "camera-path buffers"); }
     e = hipEventCreate(&c->evStart);
     if (e == hipSuccess) e = hipEventCreate(&c->evStop);
@@ -392,7 +398,7 @@ void rt_destroy(rt_ctx* ctx) {
     if (ctx->hSplitWaves) (void)hipHostFree(const_cast<uint32_t*>(ctx->hSplitWaves));
     if (ctx->dPathCams) (void)hipFree(ctx->dPathCams);
     if (ctx->hPathCams) (void)hipHostFree(ctx->hPathCams);
-    if (ctx->pathCamsFree) (void)hipEventDestroy(ctx->pathCamsFree);
+    for (hipEvent_t ev : ctx->pathCamsFree) if (ev) (void)hipEventDestroy(ev);
     if (ctx->evStart) (void)hipEventDestroy(ctx->evStart);
     if (ctx->evStop) (void)hipEventDestroy(ctx->evStop);
     delete ctx;
@@ -651,9 +657,11 @@ int renderPath(rt_ctx* ctx, int width, int height, int rank, int world, bool com
     if (p.ownedTiles <= 0) return RT_OK;
     if ((unsigned long long)rt::launchGridBlocks(p) * (unsigned long long)nFrames > 0x7fffffffull)
         return fail(RT_ERR_CAPACITY, "too many workgroups for one launch: render the path in shorter pieces");
-    RT_HIP(hipEventSynchronize(ctx->pathCamsFree));      // the previous path call's copy has left the staging buffer
+    const int slot = (int)(ctx->pathCalls++ % rt_ctx::kPathStaging);
+    float* const staging = ctx->hPathCams + (size_t)slot * 16 * RT_MAX_PATH_FRAMES;
+    RT_HIP(hipEventSynchronize(ctx->pathCamsFree[slot]));      // the copy of four path calls ago has left this staging slot
     for (int f = 0; f < nFrames; f++) {
-        float* d = ctx->hPathCams + 16 * (size_t)f;
+        float* d = staging + 16 * (size_t)f;
         const rt_camera& c = cams[f];
         const float v[13] = {c.position.x, c.position.y, c.position.z, c.up.x, c.up.y, c.up.z, c.right.x, c.right.y, c.right.z,
                              c.direction.x, c.direction.y, c.direction.z, c.fovFactor};
@@ -662,8 +670,8 @@ int renderPath(rt_ctx* ctx, int width, int height, int rank, int world, bool com
         const float len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
         d[13] = v[0] / len; d[14] = v[1] / len; d[15] = v[2] / len;
     }
-    RT_HIP(hipMemcpyAsync(ctx->dPathCams, ctx->hPathCams, sizeof(float) * 16 * (size_t)nFrames, hipMemcpyHostToDevice, stream));
-    RT_HIP(hipEventRecord(ctx->pathCamsFree, stream));
+    RT_HIP(hipMemcpyAsync(ctx->dPathCams, staging, sizeof(float) * 16 * (size_t)nFrames, hipMemcpyHostToDevice, stream));
+    RT_HIP(hipEventRecord(ctx->pathCamsFree[slot], stream));
     if (ctx->sphere0Dirty || ctx->plane0Dirty) {
         RT_HIP(rt::launchPatchTables(ctx->sphere0Dirty ? const_cast<rt::F4*>(ctx->scene.sphGeom) : nullptr, ctx->sphere0Geom,
                                      ctx->plane0Dirty ? const_cast<rt::F4*>(ctx->scene.plnMat) : nullptr, ctx->plane0Mat0, stream));
@@ -762,6 +770,22 @@ int rt_untile_strided_device(rt_ctx* ctx, int width, int height, int world, cons
     RT_HIP(hipSetDevice(ctx->device));
     RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb), width, height, world, tilesAlong(width),
                             rank_stride_bytes, static_cast<hipStream_t>(hip_stream)));
+    return RT_OK;
+}
+
+int rt_untile_batch_device(rt_ctx* ctx, int width, int height, int world, const void* d_gathered, size_t rank_stride_bytes,
+                           size_t frame_stride_bytes, int n_frames, void* d_rgb_frames, void* hip_stream) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    if (width <= 0 || height <= 0 || world <= 0) return fail(RT_ERR_INVALID, "bad frame or world size");
+    if (n_frames <= 0 || n_frames > 65535) return fail(RT_ERR_INVALID, "n_frames must be 1 .. 65535");
+    if (!d_gathered || !d_rgb_frames) return fail(RT_ERR_INVALID, "null device buffer");
+    const size_t tileBytes = rt_tile_buffer_bytes(width, height, world);
+    if (frame_stride_bytes < tileBytes || frame_stride_bytes % 16 != 0) return fail(RT_ERR_INVALID, "frame stride must be a multiple of 16 and hold a tile buffer");
+    if (rank_stride_bytes % 16 != 0 || rank_stride_bytes < frame_stride_bytes * (size_t)(n_frames - 1) + tileBytes)
+        return fail(RT_ERR_INVALID, "rank stride must be a multiple of 16 and hold the tile buffers of all frames");
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb_frames), width, height, world, tilesAlong(width),
+                            rank_stride_bytes, static_cast<hipStream_t>(hip_stream), n_frames, frame_stride_bytes));
     return RT_OK;
 }
 

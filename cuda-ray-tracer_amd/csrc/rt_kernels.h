@@ -45,6 +45,6 @@ struct StaticScratch { uint32_t* words; int costSlot; long long orderKey; };
 hipError_t staticScratch(int device, StaticScratch** out);
 
 hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX,
-                        size_t perRankBytes, hipStream_t stream);
+                        size_t perRankBytes, hipStream_t stream, int frames = 1, size_t frameStrideIn = 0);
 
 }  // namespace rt

@@ -162,6 +162,16 @@ int rt_untile_device(rt_ctx* ctx, int width, int height, int world, const void* 
 int rt_untile_strided_device(rt_ctx* ctx, int width, int height, int world, const void* d_gathered,
                              size_t rank_stride_bytes, void* d_rgb, void* hip_stream);
 
+/*
+ * The frames of a whole gather batch with one launch: frame j of rank r starts at d_gathered + r * rank_stride_bytes +
+ * j * frame_stride_bytes (both multiples of 16), and the reassembled frames are written one after the other into
+ * d_rgb_frames (n_frames x width x height x 3 bytes).  One launch instead of n: beside render launches that occupy the
+ * GPU a reassembly kernel mostly waits for registers to come free, once per launch.  No reference counterpart.
+ */
+int rt_untile_batch_device(rt_ctx* ctx, int width, int height, int world, const void* d_gathered,
+                           size_t rank_stride_bytes, size_t frame_stride_bytes, int n_frames, void* d_rgb_frames,
+                           void* hip_stream);
+
 /* Ray count of the current scene/state at this resolution, from the device's own counters (blocking). */
 int rt_count_rays(rt_ctx* ctx, int width, int height, rt_frame_stats* stats);
 

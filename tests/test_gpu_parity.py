@@ -373,3 +373,39 @@ def test_strided_untile_for_batched_gathers(renderer):
     assert not frame.any()
     with pytest.raises(binding.RtError):
         renderer.untile_strided_device(w, h, world, gathered.data_ptr(), per - 16, frame.data_ptr(), stream)
+
+
+@pytest.mark.parametrize("size", [(640, 360), (656, 200), (333, 201)])
+def test_batched_untile_reassembles_every_frame_of_a_gather(renderer, size):
+    """rt_untile_batch_device: the frames of a gather batch (rank r's buffer of frame j at r * rank_stride + j * frame_stride)
+    with one launch; every frame equals its one-launch rendering.  The three widths take the three reassembly kernels
+    (whole tiles per row, multiples of 16 pixels, any width)."""
+    import torch
+    from cuda_ray_tracer_amd import binding
+    w, h = size
+    world, frames = 3, 3
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.2)
+    built = scenes.build_scene(spec)
+    renderer.upload(built.desc)
+    per = binding.tile_buffer_bytes(w, h, world)
+    gathered = torch.zeros(per * frames * world, dtype=torch.uint8, device="cuda:0")
+    out = torch.zeros(frames * w * h * 3, dtype=torch.uint8, device="cuda:0")
+    stream = torch.cuda.current_stream().cuda_stream
+    direct = []
+    for j in range(frames):
+        cam = built.camera
+        if j:
+            pos, yaw, pitch = scenes.camera_path_pose(spec, 40 * j)
+            cam = binding.camera_look(pos, spec.fov, yaw, pitch)
+        renderer.set_state(cam, cfg)
+        direct.append(renderer.render(w, h)[0])
+        for rank in range(world):
+            renderer.render_tiles_device(w, h, rank, world, gathered.data_ptr() + rank * frames * per + j * per, per, stream)
+    renderer.untile_batch_device(w, h, world, gathered.data_ptr(), frames * per, per, frames, out.data_ptr(), stream)
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().reshape(frames, h, w, 3)
+    for j in range(frames):
+        assert np.array_equal(got[j], direct[j]), f"frame {j}"
+    assert not np.array_equal(direct[0], direct[1])
+    with pytest.raises(binding.RtError):
+        renderer.untile_batch_device(w, h, world, gathered.data_ptr(), (frames - 1) * per, per, frames, out.data_ptr(), stream)   # rank stride too small for three frames
