@@ -86,6 +86,7 @@ struct rt_ctx {
     uint32_t* dHeavyBits = nullptr;   // kMaxSplitBlocks / 32 + 8
     rt::SplitState* dSplitState = nullptr;
     int splitSlot = 0;                // slot of dSplitState the next selection writes
+    int framesSinceRank = 0, rankedFrames = 0;   // see kRankPeriod
     int framesSinceSelection = 0;     // while nothing is split the selection only runs every kIdleSelectionPeriod-th frame
     int split = 1;                    // 0 disables splitting
     int splitRatio256 = 512;          // a block is split if it costs more than this share (in 1/256) of the evenly spread frame time
@@ -121,6 +122,8 @@ void freeScene(rt_ctx* c) {
     c->haveScene = false;
 }
 
+constexpr int kRankPeriod = 4;          // tiles are ranked after every kRankPeriod-th frame ...
+constexpr int kRankWarmup = 3;          // ... once the first kRankWarmup frames of a geometry have each been ranked
 constexpr int kIdleSelectionPeriod = 8;
 constexpr int kActiveSelectionPeriod = 2;
 constexpr int kMaxOrderedTiles = 1 << 16;   // frames with more tiles per rank are rendered in plain tile order
@@ -239,7 +242,17 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
     // with launch.split the grid starts with the split waves of the heaviest blocks (their records follow the regular ones)
     RT_HIP(rt::launchRender(ctx->scene, launch, out, ids, tbuf, counters, instrumented, stream, waveClocks,
                             plan.haveOrder ? ctx->dTileOrder : nullptr, cur, fb));
-    RT_HIP(rt::launchRankTiles(cur, ctx->dTileOrder, nxt, p.ownedTiles, stream));
+    // The tiles are ranked after each of the first frames of a geometry, then after every fourth (RT_RANK_PERIOD overrides): the
+    // costs keep accumulating their maxima in between, the order changes slowly, and the ranking launch with the gap around it is
+    // 3 % of a 1080p frame that nothing else would wait for.
+    static const int rankPeriod = std::getenv("RT_RANK_PERIOD") ? std::max(1, std::atoi(std::getenv("RT_RANK_PERIOD"))) : kRankPeriod;
+    const bool rank = !plan.haveOrder || ctx->rankedFrames < kRankWarmup || ++ctx->framesSinceRank >= rankPeriod;
+    if (!plan.haveOrder) ctx->rankedFrames = 0;
+    if (rank) {
+        RT_HIP(rt::launchRankTiles(cur, ctx->dTileOrder, nxt, p.ownedTiles, stream));
+        ctx->framesSinceRank = 0;
+        if (ctx->rankedFrames < kRankWarmup) ctx->rankedFrames++;
+    }
     // While the last selection split nothing (host hint, possibly a frame or two old), look again only now and then: the
     // block costs keep accumulating their maxima in between, and a frame that does not split saves two small launches.
     const bool idle = !launch.split && ctx->hSplitWaves && *ctx->hSplitWaves == 0u;
@@ -254,7 +267,7 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
                                      ctx->splitRatio256, ctx->splitFloor, ctx->splitStartTenths, stream));
         ctx->splitSlot ^= 1;
     }
-    ctx->costSlot ^= 1;
+    if (rank) ctx->costSlot ^= 1;
     ctx->orderKey = plan.key;
     return RT_OK;
 }
