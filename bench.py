@@ -113,7 +113,7 @@ def main():
                          "launches that do not overlap), 2 on several GPUs (a rank's share of a frame is as long as its heaviest "
                          "8x8 block and leaves most of the GPU idle)")
     ap.add_argument("--tile-slots", type=int, default=3, help="several GPUs: tile-buffer slots per rank (gathers that can be in flight or being filled)")
-    ap.add_argument("--frames-per-gather", type=int, default=0, help="several GPUs: consecutive frames whose tiles one gather moves (0 = 4, from eight GPUs on 8)")
+    ap.add_argument("--frames-per-gather", type=int, default=0, help="several GPUs: consecutive frames whose tiles one gather moves (0 = 4 on two GPUs, 8 on four, 16 from eight on: a launch costs at least the run time of its heaviest block, however little it renders)")
     ap.add_argument("--device-build", type=int, default=-1, help="1: build the octrees on the GPU, 0: on the host, -1: GPU for config 5 only")
     ap.add_argument("--path-frames", type=int, default=0,
                     help="also render this many frames of the benchmark's moving-camera path (scenes.camera_path_pose): once frame by "
@@ -216,7 +216,7 @@ def main():
         # call is about that of rendering a frame's share).  Several slots: the gather of a slot (RCCL's own stream) overlaps
         # the render of the frames after it; a slot is rendered into again only when its gather has finished, so their number
         # bounds how many frames the pipeline holds.
-        batch = max(1, args.frames_per_gather if args.frames_per_gather > 0 else ((8 if share >= 8 else 4) if share > 1 else 1))
+        batch = max(1, args.frames_per_gather if args.frames_per_gather > 0 else ((16 if share >= 8 else 8 if share >= 4 else 4) if share > 1 else 1))
         slots = max(2, args.tile_slots)
         tile_bytes = binding.tile_buffer_bytes(w, h, share)
         slot_bytes = tile_bytes * batch
