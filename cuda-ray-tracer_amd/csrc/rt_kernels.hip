@@ -1302,41 +1302,36 @@ __global__ __launch_bounds__(256) void untileKernel(const uint8_t* __restrict__ 
 }
 
 // The same for frames whose width is a multiple of 16 pixels: a tile row is 96 contiguous bytes in both layouts and every
-// 16-byte piece of the frame lies inside one tile row, so a thread moves one aligned 16-byte piece.
-__global__ __launch_bounds__(256) void untileWideKernel(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ out, int width, int height,
-                                                        int world, int tilesX, size_t perRankBytes, size_t frameStrideIn) {
-    const size_t rowBytes = (size_t)width * 3;
-    gathered += (size_t)blockIdx.y * frameStrideIn; out += (size_t)blockIdx.y * rowBytes * (size_t)height;
-    const size_t o = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (o >= rowBytes * (size_t)height) return;
-    const uint32_t y = (uint32_t)(o / rowBytes), xb = (uint32_t)(o % rowBytes);
-    constexpr uint32_t kTileRowBytes = RT_TILE_PX * 3;
-    const uint32_t tile = (y / RT_TILE_PX) * (uint32_t)tilesX + xb / kTileRowBytes;
-    const uint32_t rank = tile % (uint32_t)world, local = tile / (uint32_t)world;
-    const size_t src = (size_t)rank * perRankBytes + (size_t)local * (RT_TILE_PX * kTileRowBytes) + (size_t)(y % RT_TILE_PX) * kTileRowBytes + xb % kTileRowBytes;
-    *reinterpret_cast<u4_t*>(out + o) = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(gathered + src));
-}
-
-// The same for frames whose width is a whole number of tiles: one thread moves one row of one tile (96 bytes, six 16-byte
-// pieces, contiguous in both layouts); neighbouring threads take neighbouring tiles of the same pixel row, so a wave writes
-// 6 KB of the frame in one piece.  A sixth of the waves of the kernel above: the reassembly runs beside render launches
-// that occupy every wave slot, and what it costs there is the wait for slots (1080p on a busy GPU: 26 us -> 7 us per frame).
-__global__ __launch_bounds__(256) void untileRowsKernel(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ out, int width, int height,
-                                                        int world, int tilesX, size_t perRankBytes, size_t frameStrideIn) {
-    gathered += (size_t)blockIdx.y * frameStrideIn; out += (size_t)blockIdx.y * (size_t)width * (size_t)height * 3;
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint32_t)height * (uint32_t)tilesX) return;
-    const uint32_t y = t / (uint32_t)tilesX, tx = t - y * (uint32_t)tilesX;
-    constexpr uint32_t kTileRowBytes = RT_TILE_PX * 3;
-    const uint32_t tile = (y / RT_TILE_PX) * (uint32_t)tilesX + tx;
-    const uint32_t rank = tile % (uint32_t)world, local = tile / (uint32_t)world;
-    const u4_t* src = reinterpret_cast<const u4_t*>(gathered + (size_t)rank * perRankBytes + (size_t)local * (RT_TILE_PX * kTileRowBytes) + (size_t)(y % RT_TILE_PX) * kTileRowBytes);
-    u4_t* dst = reinterpret_cast<u4_t*>(out + (size_t)y * (size_t)width * 3 + (size_t)tx * kTileRowBytes);
-    u4_t v[kTileRowBytes / 16];
+// 16-byte piece of the frame lies inside one tile row.  A wave moves kUntilePieces KB of the frame: in every step its 64 lanes
+// write 1 KB of the frame in one piece (whole cache lines) and read it as runs of 96 bytes from the tile buffers.  Few, long
+// waves: the reassembly runs beside render launches that occupy every wave slot, and what it costs there is the wait for
+// slots (1080p on a busy GPU: 26 us per frame with one 16-byte piece per thread, 7 us with six).  Alone on the GPU it moves
+// 4.5 TB/s (read + written) at 3840 x 2160; a thread that moved one tile row, six pieces 96 bytes apart from its
+// neighbour's, reached 2.2 TB/s.
+constexpr uint32_t kUntilePieces = 6;
+__global__ __launch_bounds__(256) void untilePiecesKernel(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ out, int width, int height,
+                                                          int world, int tilesX, size_t perRankBytes, size_t frameStrideIn) {
+    const uint32_t piecesPerRow = (uint32_t)width * 3 / 16, pieces = piecesPerRow * (uint32_t)height;
+    gathered += (size_t)blockIdx.y * frameStrideIn; out += (size_t)blockIdx.y * (size_t)pieces * 16;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64, lane = threadIdx.x % 64;
+    constexpr uint32_t kTileRowPieces = RT_TILE_PX * 3 / 16;
+    u4_t v[kUntilePieces];
 #pragma unroll
-    for (uint32_t k = 0; k < kTileRowBytes / 16; k++) v[k] = __builtin_nontemporal_load(src + k);
+    for (uint32_t k = 0; k < kUntilePieces; k++) {
+        const uint32_t piece = (wave * kUntilePieces + k) * 64 + lane;
+        if (piece >= pieces) break;
+        const uint32_t y = piece / piecesPerRow, xp = piece - y * piecesPerRow;
+        const uint32_t tile = (y / RT_TILE_PX) * (uint32_t)tilesX + xp / kTileRowPieces;
+        const uint32_t rank = tile % (uint32_t)world, local = tile / (uint32_t)world;
+        const size_t src = (size_t)rank * perRankBytes + ((size_t)local * (RT_TILE_PX * kTileRowPieces) + (size_t)(y % RT_TILE_PX) * kTileRowPieces + xp % kTileRowPieces) * 16;
+        v[k] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(gathered + src));
+    }
 #pragma unroll
-    for (uint32_t k = 0; k < kTileRowBytes / 16; k++) dst[k] = v[k];
+    for (uint32_t k = 0; k < kUntilePieces; k++) {
+        const uint32_t piece = (wave * kUntilePieces + k) * 64 + lane;
+        if (piece >= pieces) break;
+        __builtin_nontemporal_store(v[k], reinterpret_cast<u4_t*>(out) + piece);
+    }
 }
 
 // ---------------------------------------------------------------- launch wrappers (host)
@@ -1569,14 +1564,9 @@ hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int he
     static_assert((RT_TILE_PX * 3) % 16 == 0, "a tile row must be a whole number of 16-byte pieces");
     const bool aligned = perRankBytes % 16 == 0 && (reinterpret_cast<uintptr_t>(gathered) | reinterpret_cast<uintptr_t>(out)) % 16 == 0 &&
                          (frames == 1 || (frameStrideIn % 16 == 0 && total % 16 == 0));
-    if (aligned && width % RT_TILE_PX == 0) {
-        const size_t rows = (size_t)height * (size_t)tilesX;
-        hipLaunchKernelGGL(untileRowsKernel, dim3((unsigned)((rows + 255) / 256), (unsigned)frames), dim3(256), 0, stream, gathered, out, width, height, world, tilesX, perRankBytes, frameStrideIn);
-        return hipGetLastError();
-    }
-    if (aligned && width % 16 == 0) {
-        const size_t pieces = total / 16;
-        hipLaunchKernelGGL(untileWideKernel, dim3((unsigned)((pieces + 255) / 256), (unsigned)frames), dim3(256), 0, stream, gathered, out, width, height, world, tilesX, perRankBytes, frameStrideIn);
+    if (aligned && width % 16 == 0 && total / 16 < (1ull << 31)) {
+        const size_t waves = (total / 16 + 64 * kUntilePieces - 1) / (64 * kUntilePieces);
+        hipLaunchKernelGGL(untilePiecesKernel, dim3((unsigned)((waves + 3) / 4), (unsigned)frames), dim3(256), 0, stream, gathered, out, width, height, world, tilesX, perRankBytes, frameStrideIn);
         return hipGetLastError();
     }
     size_t threads = (total + 3) / 4;
