@@ -1245,7 +1245,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
             if (!STATS && c != kCntRays) continue;
             uint32_t v = vals[c];
             for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-            if (lane == 0 && v) atomicAdd(&counters[c], (unsigned long long)v);
+            if (lane == 0 && v) atomicAdd(&counters[(blockIdx.x % (uint32_t)kCounterSlots) * (uint32_t)kCounterStride + c], (unsigned long long)v);
         }
     }
 }
