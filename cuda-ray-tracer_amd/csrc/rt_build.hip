@@ -8,8 +8,9 @@
 //   1. one thread per triangle: bounds, centre, 30-bit Morton code of the centre inside the model's bounds;
 //      key = (model, code)
 //   2. radix sort of (key, triangle)
-//   3. top-down, one launch per nesting level, one thread per node: the node's eight children are the runs of equal
-//      3-bit digit at the node's Morton level (found by binary search, levels without a split are skipped); a run with few
+//   3. top-down, one launch per nesting level, one thread per node: the node's children are the runs of equal
+//      3-bit digit at the node's Morton level (found by binary search, levels without a split are skipped), and while
+//      slots are free the run with the largest cell is replaced by its own runs; a run with few
 //      triangles, identical codes or at the depth cap becomes a leaf, the others get contiguous node slots
 //   4. bottom-up, one launch per level: child boxes from the triangles of leaf children and the unions of internal
 //      children, padded and quantised exactly as on the host (rt_node_codec.h)
@@ -20,6 +21,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -108,11 +110,62 @@ __global__ void seedRootsKernel(const BuildModelDev* __restrict__ models, int mo
 
 __device__ __forceinline__ uint32_t digitAt(uint64_t key, int level) { return (uint32_t)(key >> (3 * (kMortonLevels - 1 - level))) & 7u; }
 
+// First Morton level >= from at which the sorted range [a, b) splits: its first and last key differ there.
+__device__ __forceinline__ int firstSplitLevel(const uint64_t* __restrict__ keys, uint32_t a, uint32_t b, int from) {
+    int level = from < kMortonLevels - 1 ? from : kMortonLevels - 1;
+    while (level < kMortonLevels - 1 && digitAt(keys[a], level) == digitAt(keys[b - 1], level)) level++;
+    return level;
+}
+
+// The non-empty runs of equal digit at `level` in the sorted range [a, b), in digit order; returns their number.
+__device__ __forceinline__ int cutRuns(const uint64_t* __restrict__ keys, uint32_t a, uint32_t b, int level, uint32_t* runA, uint32_t* runB) {
+    int runs = 0;
+    uint32_t from = a;
+    for (uint32_t c = 0; c < 8 && from < b; c++) {
+        // end of the run with digit c = first position whose digit is > c
+        uint32_t lo = from, hi = b;
+        while (lo < hi) {
+            const uint32_t mid = lo + ((hi - lo) >> 1);
+            if (digitAt(keys[mid], level) <= c) lo = mid + 1; else hi = mid;
+        }
+        if (lo > from) { runA[runs] = from; runB[runs] = lo; runs++; }
+        from = lo;
+    }
+    return runs;
+}
+
+// A run cut at `level` below a node of nesting depth `depth` stays a leaf if it is small, cannot be cut further or would
+// nest deeper than the cap.
+__device__ __forceinline__ bool isLeafRun(const uint64_t* __restrict__ keys, uint32_t a, uint32_t b, int level, int depth, int leafTriangles, int maxDepth) {
+    return (int)(b - a) <= leafTriangles || depth + 1 >= maxDepth || level == kMortonLevels - 1 || keys[a] == keys[b - 1];
+}
+
+__device__ __forceinline__ uint32_t compactBits10(uint32_t v) {
+    v &= 0x09249249u;
+    v = (v | (v >> 2)) & 0x030C30C3u;
+    v = (v | (v >> 4)) & 0x0300F00Fu;
+    v = (v | (v >> 8)) & 0x030000FFu;
+    v = (v | (v >> 16)) & 0x3FFu;
+    return v;
+}
+
+// Twice the centre (grid units, 1024 per axis) and the edge length of the Morton cell that `key` lies in when the digits
+// of levels 0 .. level are fixed; level -1 = the whole grid.
+__device__ __forceinline__ void cellCentre2(uint64_t key, int level, int* centre2, int& size) {
+    const uint32_t code = (uint32_t)key & 0x3FFFFFFFu;
+    const int shift = kMortonLevels - 1 - level;      // 10 for the whole grid
+    size = 1 << shift;
+    for (int a = 0; a < 3; a++) {
+        const int q = (int)compactBits10(code >> a);
+        centre2[a] = 2 * ((q >> shift) << shift) + size;
+    }
+}
+
 // Step 3.  Writes the topology words of each node record (4-7 and 20-27); the boxes follow in boxKernel.
 __global__ __launch_bounds__(128) void splitKernel(const uint32_t* __restrict__ nodeList, uint32_t first, uint32_t count,
                                                   BuildNode* __restrict__ bn, const uint64_t* __restrict__ keys, F4* __restrict__ nodes,
                                                   uint8_t* __restrict__ lastFlag, uint32_t* __restrict__ counters, uint32_t capacity,
-                                                  int leafTriangles, int maxDepth) {
+                                                  int leafTriangles, int maxDepth, bool fold) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     const uint32_t idx = nodeList ? nodeList[i] : first + i;
@@ -129,24 +182,78 @@ __global__ __launch_bounds__(128) void splitKernel(const uint32_t* __restrict__ 
     } else {
         // first Morton level at which the range splits: the first and last key differ there (the keys are sorted and agree on
         // every level above the node's own)
-        int level = n.level;
-        while (level < kMortonLevels - 1 && digitAt(keys[n.a], level) == digitAt(keys[n.b - 1], level)) level++;
-        uint32_t internal = 0;
-        uint32_t childStart[8], childEnd[8];
-        uint32_t from = n.a;
-        for (uint32_t c = 0; c < 8; c++) {
-            // end of the run with digit c = first position whose digit is > c
-            uint32_t lo = from, hi = n.b;
-            while (lo < hi) {
-                const uint32_t mid = lo + ((hi - lo) >> 1);
-                if (digitAt(keys[mid], level) <= c) lo = mid + 1; else hi = mid;
+        const int level = firstSplitLevel(keys, n.a, n.b, n.level);
+        // The children: runs of equal digit at that level.  An octree of a surface uses about half of a node's eight slots;
+        // as long as there is room, the internal child with the largest cell (then the most triangles) is replaced by its
+        // own runs, so that a ray visits fewer nodes for the same triangles.
+        uint32_t kidA[8], kidB[8];
+        int kidLevel[8];                      // Morton level the kid's run was cut at
+        bool kidLeaf[8], kidTried[8];
+        int kids = 0;
+        {
+            uint32_t runA[8], runB[8];
+            const int runs = cutRuns(keys, n.a, n.b, level, runA, runB);
+            for (int r = 0; r < runs; r++) {
+                kidA[kids] = runA[r]; kidB[kids] = runB[r]; kidLevel[kids] = level; kidTried[kids] = false;
+                kidLeaf[kids] = isLeafRun(keys, runA[r], runB[r], level, n.depth, leafTriangles, maxDepth);
+                kids++;
             }
-            const uint32_t a = from, b = lo;
-            from = lo;
-            childStart[c] = a; childEnd[c] = b;
-            if (b <= a) continue;
-            const bool leaf = (int)(b - a) <= leafTriangles || n.depth + 1 >= maxDepth || level == kMortonLevels - 1 || keys[a] == keys[b - 1];
-            if (leaf) { lmask |= 1u << c; words[20 + c] = a; lastFlag[b - 1] = 1; }
+        }
+        while (fold && kids < 8) {
+            int pick = -1;
+            for (int k = 0; k < kids; k++) {
+                if (kidLeaf[k] || kidTried[k]) continue;
+                if (pick < 0 || kidLevel[k] < kidLevel[pick] || (kidLevel[k] == kidLevel[pick] && kidB[k] - kidA[k] > kidB[pick] - kidA[pick])) pick = k;
+            }
+            if (pick < 0) break;
+            kidTried[pick] = true;
+            const int sub = firstSplitLevel(keys, kidA[pick], kidB[pick], kidLevel[pick] + 1);
+            uint32_t runA[8], runB[8];
+            const int runs = cutRuns(keys, kidA[pick], kidB[pick], sub, runA, runB);
+            if (kids - 1 + runs > 8) continue;
+            for (int r = 0; r < runs; r++) {
+                const int k = r == 0 ? pick : kids++;
+                kidA[k] = runA[r]; kidB[k] = runB[r]; kidLevel[k] = sub; kidTried[k] = false;
+                kidLeaf[k] = isLeafRun(keys, runA[r], runB[r], sub, n.depth, leafTriangles, maxDepth);
+            }
+        }
+        // Slots: bit a of a slot index means "towards +a within the node", which the traversal's front-to-back order
+        // (slot ^ ray octant) relies on; the order is a heuristic, hits do not depend on it.  Greedily the best total of
+        // (centre of the kid's cell - centre of the node's cell) . (slot direction); unfolded kids get their own digit.
+        int slotOfKid[8];
+        {
+            int nodeCentre[3], nodeSize;
+            cellCentre2(keys[n.a], level - 1, nodeCentre, nodeSize);
+            float score[8][8];
+            for (int k = 0; k < kids; k++) {
+                int c[3], size;
+                cellCentre2(keys[kidA[k]], kidLevel[k], c, size);
+                float rel[3];
+                for (int ax = 0; ax < 3; ax++) rel[ax] = (float)(c[ax] - nodeCentre[ax]) / (float)(2 * nodeSize);
+                for (int sl = 0; sl < 8; sl++)
+                    score[k][sl] = ((sl & 1) ? rel[0] : -rel[0]) + ((sl & 2) ? rel[1] : -rel[1]) + ((sl & 4) ? rel[2] : -rel[2]);
+                slotOfKid[k] = -1;
+            }
+            uint32_t slotTaken = 0;
+            for (int round = 0; round < kids; round++) {
+                int bk = -1, bs = -1;
+                for (int k = 0; k < kids; k++) {
+                    if (slotOfKid[k] >= 0) continue;
+                    for (int sl = 0; sl < 8; sl++) {
+                        if ((slotTaken >> sl) & 1u) continue;
+                        if (bk < 0 || score[k][sl] > score[bk][bs]) { bk = k; bs = sl; }
+                    }
+                }
+                slotOfKid[bk] = bs; slotTaken |= 1u << bs;
+            }
+        }
+        int kidOfSlot[8] = {-1, -1, -1, -1, -1, -1, -1, -1};
+        for (int k = 0; k < kids; k++) kidOfSlot[slotOfKid[k]] = k;
+        uint32_t internal = 0;
+        for (int c = 0; c < 8; c++) {
+            const int k = kidOfSlot[c];
+            if (k < 0) continue;
+            if (kidLeaf[k]) { lmask |= 1u << c; words[20 + c] = kidA[k]; lastFlag[kidB[k] - 1] = 1; }
             else { imask |= 1u << c; internal++; }
         }
         atomicAdd(&counters[kCtrLeaves], (uint32_t)__builtin_popcount(lmask));
@@ -156,8 +263,9 @@ __global__ __launch_bounds__(128) void splitKernel(const uint32_t* __restrict__ 
             uint32_t next = childBase;
             for (int c = 0; c < 8; c++) {
                 if (!((imask >> c) & 1u)) continue;
+                const int k = kidOfSlot[c];
                 BuildNode ch;
-                ch.a = childStart[c]; ch.b = childEnd[c]; ch.model = n.model; ch.level = (uint16_t)(level + 1); ch.depth = (uint16_t)(n.depth + 1);
+                ch.a = kidA[k]; ch.b = kidB[k]; ch.model = n.model; ch.level = (uint16_t)(kidLevel[k] + 1); ch.depth = (uint16_t)(n.depth + 1);
                 bn[next++] = ch;
             }
             atomicMax(&counters[kCtrDepth], (uint32_t)n.depth + 2u);
@@ -341,8 +449,9 @@ hipError_t buildMeshesOnDevice(const rt_scene_desc& scene, const FlatScene& flat
     std::vector<Range> levels;
     uint32_t done = forestNodes;
     const int maxDepth = flat.params.maxDepth, leafTriangles = flat.params.leafTriangles;
+    static const bool fold = !std::getenv("RT_DEVICE_FOLD") || std::atoi(std::getenv("RT_DEVICE_FOLD")) != 0;    // experiment switch: 0 = one Morton digit per node
     hipLaunchKernelGGL(splitKernel, dim3((modelCount + 127) / 128), dim3(128), 0, nullptr, rootList, 0u, (uint32_t)modelCount, bn, keysOut, nodes,
-                       lastFlag, counters, capacity, leafTriangles, maxDepth);
+                       lastFlag, counters, capacity, leafTriangles, maxDepth, fold);
     RT_TRY(hipGetLastError());
     uint32_t host[kCtrCount];
     for (;;) {
@@ -353,7 +462,7 @@ hipError_t buildMeshesOnDevice(const rt_scene_desc& scene, const FlatScene& flat
         if (created == 0) break;
         levels.push_back(Range{done, created});
         hipLaunchKernelGGL(splitKernel, dim3((created + 127) / 128), dim3(128), 0, nullptr, (const uint32_t*)nullptr, done, created, bn, keysOut, nodes,
-                           lastFlag, counters, capacity, leafTriangles, maxDepth);
+                           lastFlag, counters, capacity, leafTriangles, maxDepth, fold);
         RT_TRY(hipGetLastError());
         done += created;
     }
