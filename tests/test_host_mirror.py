@@ -231,3 +231,18 @@ def test_headless_frame_loop_with_keys_writes_a_sequence(model_dir, tmp_path):
     assert frames[0] != frames[1] and frames[2] != frames[3] and frames[3] != frames[4]
     assert frames[4] == frames[5]                       # the blank key holds nothing: the same frame again
     assert frames[5] == out.read_bytes()
+
+
+def test_view_without_a_display_reports_it_and_touches_no_gpu(tmp_path):
+    """rt_view is the reference's window (Xlib + GLX + HIP's OpenGL interop).  No test machine has an X display, so what can
+    be checked is the start-up contract: it opens the window before anything else, says why it cannot and exits with 3."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(host_lib.HOST_SO), "rt_view")
+    if not os.path.exists(exe):
+        pytest.skip("rt_view is only built where the X11 and OpenGL headers are installed")
+    env = {k: v for k, v in os.environ.items() if k not in ("DISPLAY", "WAYLAND_DISPLAY")}
+    res = subprocess.run([exe, "--size", "64x48", "--frames", "1"], capture_output=True, text=True, timeout=60, env=env)
+    assert res.returncode == 3, (res.returncode, res.stderr[-500:])
+    assert "cannot open the X display" in res.stderr
+    res = subprocess.run([exe, "--size", "64"], capture_output=True, text=True, timeout=60, env=env)
+    assert res.returncode == 2
