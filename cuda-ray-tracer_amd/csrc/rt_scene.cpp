@@ -9,6 +9,9 @@
 #include "rt_node_codec.h"
 
 #include <algorithm>
+#include <thread>
+#include <memory>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -301,10 +304,72 @@ static bool modelBounds(const rt_model& m, int modelIndex, Box& tight, float& pa
     return true;
 }
 
+// Bounds and centre of every reachable triangle of a model: what the tree builder works on.
+static void fillBuildTris(const rt_model& m, int64_t nTri, std::vector<BuildTri>& btris) {
+    btris.assign((size_t)nTri, BuildTri());
+    for (int64_t t = 0; t < nTri; t++) {
+        const int32_t* ix = m.indices + 3 * t;
+        BuildTri& bt = btris[(size_t)t];
+        for (int k = 0; k < 3; k++) {
+            const rt_vec3& v = m.vertices[ix[k]].position;
+            const float p[3] = {v.x, v.y, v.z};
+            bt.box.grow(p);
+        }
+        for (int ax = 0; ax < 3; ax++) bt.centre[ax] = 0.5f * bt.box.lo[ax] + 0.5f * bt.box.hi[ax];
+    }
+}
+
+// The tree of one model, built ahead of flattenModel: the models of a scene are independent, so their trees are built on
+// several threads (144 models with 10.3 M triangles: 16 threads instead of one), and emitted one after the other.
+struct HostTree {
+    std::vector<BuildTri> tris;
+    std::unique_ptr<OctreeBuilder> builder;
+    int root = -1;
+};
+
+static bool buildTreesAhead(const rt_scene_desc& s, const OctreeParams& params, std::vector<HostTree>& trees) {
+    std::vector<std::pair<int64_t, int>> work;      // (triangles, model), largest first
+    int64_t total = 0;
+    for (int i = 0; i < s.modelCount; i++) {
+        const rt_model& m = s.models[i];
+        const int64_t nTri = reachableTriangles(m.indicesCount);
+        if (nTri == 0 || (m.octree && m.octree->nodeCount > 0)) continue;
+        work.emplace_back(nTri, i);
+        total += nTri;
+    }
+    int threads = (int)std::min<size_t>({work.size(), (size_t)std::max(1u, std::thread::hardware_concurrency()), (size_t)16});
+    if (const char* e = std::getenv("RT_BUILD_THREADS")) threads = std::max(1, std::min(threads, std::atoi(e)));
+    if (threads < 2 || total < 50000) return true;      // flattenModel builds the trees itself
+    std::sort(work.begin(), work.end(), [](const std::pair<int64_t, int>& a, const std::pair<int64_t, int>& b) { return a.first > b.first || (a.first == b.first && a.second < b.second); });
+    std::atomic<size_t> next{0};
+    std::atomic<bool> failed{false};
+    auto run = [&]() {
+        for (size_t k = next.fetch_add(1); k < work.size() && !failed.load(); k = next.fetch_add(1)) {
+            try {
+                HostTree& t = trees[(size_t)work[k].second];
+                fillBuildTris(s.models[work[k].second], work[k].first, t.tris);
+                t.builder.reset(new OctreeBuilder(t.tris, params));
+                t.root = t.builder->build();
+            } catch (...) {
+                failed.store(true);
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    try {
+        for (int k = 1; k < threads; k++) pool.emplace_back(run);
+    } catch (...) {
+        // fewer threads than asked for: the ones that started and this one share the work
+    }
+    run();
+    for (std::thread& t : pool) t.join();
+    return !failed.load();
+}
+
 // Emits the octree and triangle records of one model into the shared arrays.  `rootIndex` is the node the forest
 // reserved for the model's root (unused for a model without reachable triangles); `tight` / `pad` come from modelBounds.
 static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& params, uint32_t rootIndex, const Box& tight,
-                         float pad, bool onDevice, FlatScene& out, std::string& err) {
+                         float pad, bool onDevice, HostTree& ahead, FlatScene& out, std::string& err) {
     const int64_t nTri = reachableTriangles(m.indicesCount);
     const uint32_t triBase = (uint32_t)out.triangleCount;
 
@@ -318,18 +383,14 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
             return false;
         }
     }
-    std::vector<BuildTri> btris(onDevice ? 0 : (size_t)nTri);
+    // the tree may have been built ahead (buildTreesAhead); otherwise it is built here
+    std::vector<BuildTri> btris;
+    if (!onDevice && !pre && !ahead.builder) fillBuildTris(m, nTri, btris);
     for (int64_t t = 0; t < nTri && !onDevice; t++) {
         const int32_t* ix = m.indices + 3 * t;
         const rt_vertex& a = m.vertices[ix[0]];
         const rt_vertex& b = m.vertices[ix[1]];
         const rt_vertex& c = m.vertices[ix[2]];
-        BuildTri& bt = btris[(size_t)t];
-        const float pa[3] = {a.position.x, a.position.y, a.position.z};
-        const float pb[3] = {b.position.x, b.position.y, b.position.z};
-        const float pc[3] = {c.position.x, c.position.y, c.position.z};
-        bt.box.grow(pa); bt.box.grow(pb); bt.box.grow(pc);
-        for (int ax = 0; ax < 3; ax++) bt.centre[ax] = 0.5f * bt.box.lo[ax] + 0.5f * bt.box.hi[ax];
 
         // shading attributes, original triangle order
         F4 rec[kAttrFloat4s];
@@ -376,12 +437,15 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
         out.deviceModels.push_back(dm);
     }
 
-    OctreeBuilder builder(btris, params);
-    int root = (onDevice || pre) ? -1 : builder.build();
+    OctreeBuilder ownBuilder(btris, params);
+    OctreeBuilder& builder = ahead.builder ? *ahead.builder : ownBuilder;
+    int root = (onDevice || pre) ? -1 : (ahead.builder ? ahead.root : builder.build());
 
+    std::vector<int> leafIds;      // reused by every leaf of the model
     auto emitLeaf = [&](const TreeNode& n) -> uint32_t {
         uint32_t start = (uint32_t)(out.tris.size() / 3);
-        std::vector<int> ids(builder.perm_.begin() + n.first, builder.perm_.begin() + n.first + n.count);
+        leafIds.assign(builder.perm_.begin() + n.first, builder.perm_.begin() + n.first + n.count);
+        std::vector<int>& ids = leafIds;
         std::sort(ids.begin(), ids.end());
         for (size_t i = 0; i < ids.size(); i++) {
             const int32_t* ix = m.indices + 3 * (int64_t)ids[i];
@@ -630,8 +694,17 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err, bool
         out.nodes.resize(kNodeFloat4s);
         buildForest(items, 0, (int)items.size(), 0u, 0, out, rootIndex, forestDepth);
     }
+    if (!meshesOnDevice) {
+        int64_t total = 0;
+        for (int i = 0; i < s.modelCount; i++) total += reachableTriangles(s.models[i].indicesCount);
+        out.attrs.reserve((size_t)total * kAttrFloat4s);
+        out.tris.reserve(((size_t)total + kSpareTriangles) * 3);
+    }
+    std::vector<HostTree> ahead((size_t)s.modelCount);
+    if (!meshesOnDevice && !buildTreesAhead(s, params, ahead)) { err = "out of memory while building the octrees"; return false; }
     for (int i = 0; i < s.modelCount; i++) {
-        if (!flattenModel(s.models[i], i, params, rootIndex[(size_t)i], tight[(size_t)i], pad[(size_t)i], meshesOnDevice, out, err)) return false;
+        if (!flattenModel(s.models[i], i, params, rootIndex[(size_t)i], tight[(size_t)i], pad[(size_t)i], meshesOnDevice, ahead[(size_t)i], out, err)) return false;
+        ahead[(size_t)i] = HostTree();      // the tree is emitted: release it
     }
     out.forestDepth = forestDepth;
     out.params = params;
