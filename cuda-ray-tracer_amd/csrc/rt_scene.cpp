@@ -9,6 +9,7 @@
 #include "rt_node_codec.h"
 
 #include <algorithm>
+#include <array>
 #include <thread>
 #include <memory>
 #include <atomic>
@@ -62,6 +63,7 @@ public:
         if (params_.sah) {
             // binary tree by surface-area heuristic; widen() then folds it into nodes of up to eight children
             root = buildSah(0, (int)tris_.size(), 0);
+            if (params_.optimalCollapse) prepareCollapse(root);
             widen(root);
             deepest = 0;
             capDepth(root, 0);
@@ -208,8 +210,15 @@ private:
     void widen(int ni) {
         if (nodes[ni].leaf) return;
         std::vector<int> kids;
-        for (int c = 0; c < 8; c++) if (nodes[ni].child[c] >= 0) kids.push_back(nodes[ni].child[c]);
-        for (;;) {
+        if (!collapseCost_.empty() && nodes[ni].child[0] >= 0 && nodes[ni].child[1] >= 0) {
+            float cost;
+            const int k = bestSplit(ni, 8, cost);
+            collectKids(nodes[ni].child[0], k, kids);
+            collectKids(nodes[ni].child[1], 8 - k, kids);
+        } else {
+            for (int c = 0; c < 8; c++) if (nodes[ni].child[c] >= 0) kids.push_back(nodes[ni].child[c]);
+        }
+        for (; collapseCost_.empty();) {
             int pick = -1;
             float pickArea = -1.0f;
             for (size_t i = 0; i < kids.size(); i++) {
@@ -254,6 +263,52 @@ private:
         for (int c = 0; c < 8; c++) if (slotOf[c] >= 0) widen(slotOf[c]);
     }
 
+    // Which binary nodes stay nodes: every node that stays costs its surface area (the chance that a ray visits it), a node
+    // holds at most eight children, leaves cost the same wherever they hang.  collapseCost_[n][j - 1] = least total area below
+    // binary node n when n may put up to j children into its parent: either n stays (one child: area(n) + the best use of its
+    // own eight places) or n is opened and its two children share the j places.
+    void prepareCollapse(int root) {
+        collapseCost_.assign(nodes.size(), std::array<float, 8>());
+        // children have larger indices than their parents (buildSah numbers a node before it descends)
+        for (int n = (int)nodes.size() - 1; n >= root; n--) {
+            std::array<float, 8>& cost = collapseCost_[(size_t)n];
+            if (nodes[(size_t)n].leaf) { cost.fill(0.0f); continue; }
+            float open8;
+            bestSplit(n, 8, open8);
+            const float stay = area(nodes[(size_t)n].box) + open8;
+            cost[0] = stay;
+            for (int j = 2; j <= 8; j++) {
+                float open;
+                bestSplit(n, j, open);
+                cost[(size_t)j - 1] = std::min(open, stay);
+            }
+        }
+    }
+
+    // Places for the left child when internal binary node n is opened into j >= 2 places; `cost` = total area below.
+    int bestSplit(int n, int j, float& cost) const {
+        const std::array<float, 8>& l = collapseCost_[(size_t)nodes[(size_t)n].child[0]];
+        const std::array<float, 8>& r = collapseCost_[(size_t)nodes[(size_t)n].child[1]];
+        cost = std::numeric_limits<float>::infinity();
+        int bestK = 1;
+        for (int k = 1; k < j; k++) {
+            const float c = l[(size_t)k - 1] + r[(size_t)(j - k) - 1];
+            if (c < cost) { cost = c; bestK = k; }
+        }
+        return bestK;
+    }
+
+    // Binary node n with up to j places in the wide node being assembled: n itself, or the kids of its opened children.
+    void collectKids(int n, int j, std::vector<int>& kids) const {
+        if (nodes[(size_t)n].leaf || j < 2) { kids.push_back(n); return; }
+        float open, open8;
+        const int k = bestSplit(n, j, open);
+        bestSplit(n, 8, open8);
+        if (!(open < area(nodes[(size_t)n].box) + open8)) { kids.push_back(n); return; }
+        collectKids(nodes[(size_t)n].child[0], k, kids);
+        collectKids(nodes[(size_t)n].child[1], j - k, kids);
+    }
+
     static int octant(const float c[3], const float mid[3]) {
         return (c[0] > mid[0] ? 1 : 0) | (c[1] > mid[1] ? 2 : 0) | (c[2] > mid[2] ? 4 : 0);
     }
@@ -261,6 +316,7 @@ private:
     const std::vector<BuildTri>& tris_;
     OctreeParams params_;
     std::vector<int> scratch_;
+    std::vector<std::array<float, 8>> collapseCost_;
 };
 
 }  // namespace
@@ -647,6 +703,7 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err, bool
     if (s.octreeLeafTriangles > 0) { params.leafTriangles = s.octreeLeafTriangles; params.sahLeafTriangles = s.octreeLeafTriangles; }
     if (const char* e = std::getenv("RT_WIDEN")) params.widen = std::atoi(e) != 0;
     if (const char* e = std::getenv("RT_SAH")) params.sah = std::atoi(e) != 0;
+    if (const char* e = std::getenv("RT_COLLAPSE")) params.optimalCollapse = std::atoi(e) != 0;
     if (params.maxDepth > kMaxModelOctreeDepth) { err = "octreeMaxDepth exceeds " + std::to_string(kMaxModelOctreeDepth); return false; }
 
     F4 mat[3];

@@ -12,6 +12,7 @@ namespace rt {
 struct OctreeParams {
     int maxDepth = 8;        // levels of internal nodes
     bool widen = true;       // fill free child slots of a node with its grandchildren (host builder)
+    bool optimalCollapse = true; // host builder, with sah: the binary nodes that stay nodes are chosen so that their total surface area is least (RT_COLLAPSE=0: open the largest child while there is room)
     bool sah = true;         // host builder: binary surface-area splits folded into eight-wide nodes, instead of octant splits
     int sahLeafTriangles = 2; // leaf size of the surface-area builder when the caller names none (measured, config 3: 1 -> +9 %, 3 -> +0.4 %, 4 -> +1.5 %)
     int leafTriangles = 6;   // a node with at most this many triangles is a leaf (measured on MI355X, config 3: 4 -> +2 %, 8 -> +2 %, 16 -> +18 % frame time)
