@@ -126,9 +126,9 @@ void freeScene(rt_ctx* c) {
     c->haveScene = false;
 }
 
-constexpr int kRankPeriod = 4;          // tiles are ranked after every kRankPeriod-th frame ...
+constexpr int kRankPeriod = 8;          // tiles are ranked after every kRankPeriod-th frame ...
 constexpr int kRankWarmup = 3;          // ... once the first kRankWarmup frames of a geometry have each been ranked
-constexpr int kIdleSelectionPeriod = 8;
+constexpr int kIdleSelectionPeriod = 32;
 constexpr int kActiveSelectionPeriod = 2;
 constexpr int kMaxOrderedTiles = 1 << 16;   // frames with more tiles per rank are rendered in plain tile order
 
@@ -234,8 +234,20 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
     }
     uint32_t* cur = ctx->dTileCost + (size_t)ctx->costSlot * kMaxOrderedTiles;
     uint32_t* nxt = ctx->dTileCost + (size_t)(ctx->costSlot ^ 1) * kMaxOrderedTiles;
+    // While the last selection split nothing (host hint, possibly a frame or two old), the block costs are looked at only now
+    // and then: a frame that does not split saves two small launches, and a frame that neither splits nor is about to be looked
+    // at runs without the feedback altogether (the per-wave cost records and the split-list checks are 1.2 % of a 1080p frame).
+    // The frame before a selection records the costs; the frame after it carries the feedback too, because that is where the
+    // kernel reports the new selection to the host.
+    static const int activePeriod = std::getenv("RT_SELECT_PERIOD") ? std::atoi(std::getenv("RT_SELECT_PERIOD")) : kActiveSelectionPeriod;
+    static const int idlePeriod = std::getenv("RT_IDLE_SELECT_PERIOD") ? std::max(1, std::atoi(std::getenv("RT_IDLE_SELECT_PERIOD"))) : kIdleSelectionPeriod;
+    const bool idle = !launch.split && ctx->hSplitWaves && *ctx->hSplitWaves == 0u;
+    // ... and while blocks are split, every second frame: the choice changes slowly, the costs keep their maxima, and the two
+    // launches are 7 % of the time a rank needs for an eighth of the 1080p frame (RT_SELECT_PERIOD overrides).
+    const bool selectNow = feedback && (!plan.haveOrder || ctx->framesSinceSelection + 1 >= (idle ? idlePeriod : activePeriod));
+    const bool record = feedback && (!idle || selectNow || ctx->framesSinceSelection == 0);
     rt::BlockFeedback fb{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (feedback) {
+    if (record) {
         fb.blockCost = ctx->dBlockCost;
         // the selection after the previous frame wrote slot splitSlot ^ 1
         fb.extraCount = &ctx->dSplitState->used[ctx->splitSlot ^ 1];
@@ -246,7 +258,7 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
     // with launch.split the grid starts with the split waves of the heaviest blocks (their records follow the regular ones)
     RT_HIP(rt::launchRender(ctx->scene, launch, out, ids, tbuf, counters, instrumented, stream, waveClocks,
                             plan.haveOrder ? ctx->dTileOrder : nullptr, cur, fb));
-    // The tiles are ranked after each of the first frames of a geometry, then after every fourth (RT_RANK_PERIOD overrides): the
+    // The tiles are ranked after each of the first frames of a geometry, then after every eighth (RT_RANK_PERIOD overrides): the
     // costs keep accumulating their maxima in between, the order changes slowly, and the ranking launch with the gap around it is
     // 3 % of a 1080p frame that nothing else would wait for.
     static const int rankPeriod = std::getenv("RT_RANK_PERIOD") ? std::max(1, std::atoi(std::getenv("RT_RANK_PERIOD"))) : kRankPeriod;
@@ -257,14 +269,8 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
         ctx->framesSinceRank = 0;
         if (ctx->rankedFrames < kRankWarmup) ctx->rankedFrames++;
     }
-    // While the last selection split nothing (host hint, possibly a frame or two old), look again only now and then: the
-    // block costs keep accumulating their maxima in between, and a frame that does not split saves two small launches.
-    const bool idle = !launch.split && ctx->hSplitWaves && *ctx->hSplitWaves == 0u;
-    // ... and while blocks are split, every second frame: the choice changes slowly, the costs keep their maxima, and the two
-    // launches are 7 % of the time a rank needs for an eighth of the 1080p frame (RT_SELECT_PERIOD overrides).
-    static const int activePeriod = std::getenv("RT_SELECT_PERIOD") ? std::atoi(std::getenv("RT_SELECT_PERIOD")) : kActiveSelectionPeriod;
-    if (feedback && ++ctx->framesSinceSelection < (idle ? kIdleSelectionPeriod : activePeriod) && plan.haveOrder) {
-        // nothing to do this frame
+    if (feedback && !selectNow) {
+        ctx->framesSinceSelection++;
     } else if (feedback) {
         ctx->framesSinceSelection = 0;
         RT_HIP(rt::launchSelectHeavy(ctx->dBlockCost, ctx->dExtraMap, ctx->dHeavyBits, blocks, ctx->dSplitState, ctx->splitSlot, ctx->residentWaves,

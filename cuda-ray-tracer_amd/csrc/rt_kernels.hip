@@ -22,6 +22,7 @@
 
 #include "rt_device_types.h"
 #include "rt_kernels.h"
+#include "rt_math.h"
 
 namespace rt {
 
@@ -812,12 +813,12 @@ RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 v, V3 
                 V3 Ls = normalise((lightPos + ps) - point);
                 V3 r = normalise(neg(reflect(Ls, normal)));
                 float RdotV = selMax(dot(r, v), 0.0f);
-                colour = colour + (lightCol * mat.specular) * powf(RdotV, mat.shininess);
+                colour = colour + (lightCol * mat.specular) * powSpecular(RdotV, mat.shininess);
             }
         } else {
             V3 r = normalise(neg(reflect(L, normal)));
             float RdotV = selMax(dot(r, v), 0.0f);
-            colour = colour + (lightCol * mat.specular) * powf(RdotV, mat.shininess);
+            colour = colour + (lightCol * mat.specular) * powSpecular(RdotV, mat.shininess);
         }
     }
     return colour;
