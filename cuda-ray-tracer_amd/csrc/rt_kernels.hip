@@ -462,6 +462,10 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
     // what the turns below read through, for the whole loop in scalar registers
     const F4* const nodes = inGlobal(S.nodes), * const tris = inGlobal(S.tris);
     const uint32_t* const mdlInfo = inGlobal(S.mdlInfo);
+    // The octant in an entry orders the hit children and leaves front to back.  A ray that only asks whether anything is hit
+    // gains nothing from the order: its entries carry octant 0 (slot order) and the masks of a node are not permuted for it;
+    // which planes of a child box the ray enters through comes from the ray's own octant, kept beside its reciprocal direction.
+    const uint32_t entryOct = (ANYHIT && RT_RCP_IN_LDS) ? 0u : own.oct;
     // one pseudo entry per ray that resolves to the forest root
     uint32_t nodeCount, triCount = 0;
     if ((trav & kTravDirectStart) && pregated && nMdl <= kDirectStartModels && (uint32_t)nMdl * 64u + 88u <= nodeCapacity) {
@@ -472,13 +476,13 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
             const bool in = enters && ((gateBits >> j) & 1ull) != 0 && root != kNoRoot;
             const unsigned long long m = __ballot(in);
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-            if (in) lds.nodePool[nodeCount + rank] = (unsigned long long)(root | (own.oct << kNodeIndexBits)) | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
+            if (in) lds.nodePool[nodeCount + rank] = (unsigned long long)(root | (entryOct << kNodeIndexBits)) | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
             nodeCount += (uint32_t)__builtin_popcountll(m);
         }
     } else {
         const unsigned long long m = __ballot(enters);
         const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-        if (enters) lds.nodePool[rank] = (unsigned long long)(forestRoot | (own.oct << kNodeIndexBits)) | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
+        if (enters) lds.nodePool[rank] = (unsigned long long)(forestRoot | (entryOct << kNodeIndexBits)) | ((unsigned long long)((1u << 8) | (lane << 16) | (0xffu << 24)) << 32);
         nodeCount = (uint32_t)__builtin_popcountll(m);
     }
     __builtin_amdgcn_wave_barrier();
@@ -535,7 +539,7 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
                 f4_t rdHere = {0, 0, 0, 0};
                 if (RT_RCP_IN_LDS) {
                     const f4_t rr4 = lds.rayR[owner];
-                    sr.rd = xyz(rr4); sr.o = ro; sr.oct = oct;
+                    sr.rd = xyz(rr4); sr.o = ro; sr.oct = ANYHIT ? fbits(rr4.w) : oct;
                 } else {
                     rdHere = lds.rayD[owner];
                     sr = makeSlabRay(ro, xyz(rdHere));
@@ -564,7 +568,8 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
                 if (STATS) { cnt.nodeTests += __builtin_popcount(nodeImask | nodeLmask); cnt.nodeVisits++; }
                 childBase = meta.x | (oct << kNodeIndexBits); childImask = nodeImask;
                 // meta.y holds the internal mask in byte 0 and the leaf mask in byte 1: both are permuted at once
-                const uint32_t both = permuteOctants((hmask | (hmask << 8)) & meta.y & 0xffffu, oct);
+                const uint32_t bothSlots = (hmask | (hmask << 8)) & meta.y & 0xffffu;
+                const uint32_t both = (ANYHIT && RT_RCP_IN_LDS) ? bothSlots : permuteOctants(bothSlots, oct);
                 childHits = both & 0xffu;
                 pend = both >> 8;
             }
