@@ -740,9 +740,12 @@ RT_DEV void traceAnalytic(SceneK& S, V3 o, V3 d, bool skipDebugSpheres, bool tra
         f4_t g = ldu4(sphGeom + i);
         uint32_t flags = lduFlags(sphMat + 3 * i + 2);
         if (flags & 2u) continue;
+        // (the reference tests the object and then discards a debug object's hit, kernels.cu:75-83; the test has no other
+        // effect, and the flags are the same for the whole wave, so the discarded tests are not made at all - the light's
+        // marker sphere of every reference scene is such an object for every shadow and reflection ray)
+        if (skipDebugSpheres && (flags & 1u)) continue;
         float t0;
         if (sphereHit(xyz(g), g.w, o, d, t0)) {
-            if (skipDebugSpheres && (flags & 1u)) continue;
             if (t0 < best.t) { best.t = t0; best.kind = KIND_SPHERE; best.idx = i; }
         }
     }
@@ -752,9 +755,9 @@ RT_DEV void traceAnalytic(SceneK& S, V3 o, V3 d, bool skipDebugSpheres, bool tra
         for (int i = 0; i < nPln; i++) {
             uint32_t flags = lduFlags(plnMat + 3 * i + 2);
             if (flags & 2u) continue;
+            if (skipDebugPlanes && (flags & 1u)) continue;
             float t0;
             if (planeHit(xyz(ldu4(plnP + i)), xyz(ldu4(plnN + i)), o, d, t0)) {
-                if (skipDebugPlanes && (flags & 1u)) continue;
                 if (t0 < best.t) { best.t = t0; best.kind = KIND_PLANE; best.idx = i; }
             }
         }
@@ -763,9 +766,9 @@ RT_DEV void traceAnalytic(SceneK& S, V3 o, V3 d, bool skipDebugSpheres, bool tra
         const int nBox = S.nBox;
         const F4* const boxMin = inGlobal(S.boxMin), * const boxMax = inGlobal(S.boxMax), * const boxMat = inGlobal(S.boxMat);
         for (int i = 0; i < nBox; i++) {
+            if (lduFlags(boxMat + 3 * i + 2) & 1u) continue;   // boxes are always traced as reflection rays (kernels.cu:228)
             float t0;
             if (boxHit(xyz(ldu4(boxMin + i)), xyz(ldu4(boxMax + i)), o, d, t0)) {
-                if (lduFlags(boxMat + 3 * i + 2) & 1u) continue;   // boxes are always traced as reflection rays (kernels.cu:228)
                 if (t0 < best.t) { best.t = t0; best.kind = KIND_BOX; best.idx = i; }
             }
         }
@@ -778,9 +781,9 @@ RT_DEV bool shadowSpheres(SceneK& S, V3 o, V3 d) {
     for (int i = 0; i < nSph; i++) {
         f4_t g = ldu4(sphGeom + i);
         uint32_t flags = lduFlags(sphMat + 3 * i + 2);
-        if (flags & 2u) continue;
+        if (flags & 3u) continue;       // hidden, or a debug object, which never casts a shadow (kernels.cu:78)
         float t0;
-        if (sphereHit(xyz(g), g.w, o, d, t0) && !(flags & 1u)) return true;
+        if (sphereHit(xyz(g), g.w, o, d, t0)) return true;
     }
     return false;
 }
@@ -790,8 +793,9 @@ RT_DEV bool shadowBoxes(SceneK& S, V3 o, V3 d) {
     if (nBox == 0) return false;
     const F4* const boxMin = inGlobal(S.boxMin), * const boxMax = inGlobal(S.boxMax), * const boxMat = inGlobal(S.boxMat);
     for (int i = 0; i < nBox; i++) {
+        if (lduFlags(boxMat + 3 * i + 2) & 1u) continue;
         float t0;
-        if (boxHit(xyz(ldu4(boxMin + i)), xyz(ldu4(boxMax + i)), o, d, t0) && !(lduFlags(boxMat + 3 * i + 2) & 1u)) return true;
+        if (boxHit(xyz(ldu4(boxMin + i)), xyz(ldu4(boxMax + i)), o, d, t0)) return true;
     }
     return false;
 }
@@ -809,7 +813,13 @@ RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 v, V3 
         float NdotL = selMax(dot(normal, L), 0.0f);
         colour = colour + ((NdotL > 0.0f) ? (((mat.kd * lightCol) * mat.diffuse) * NdotL) : mk(0, 0, 0));
     }
-    if (flags & kCfgSpecular) {
+    // The specular term is (lightCol * specular) * pow(max(r.v, 0), shininess).  With specular = 0, a finite light colour and a
+    // shininess in [0, 1e6] (the cosine is at most 1 plus rounding, so the power is finite) it is a zero of either sign, and adding
+    // it leaves every pixel as it is: the floor, the light marker and the diffuse models of the reference's scenes have such
+    // materials.  The reflection vector and the power are skipped when no lane of the wave that is being shaded needs them.
+    const bool lightFinite = fabsf(lightCol.x) < __builtin_inff() && fabsf(lightCol.y) < __builtin_inff() && fabsf(lightCol.z) < __builtin_inff();
+    const bool specularCounts = !(mat.specular == 0.0f && mat.shininess >= 0.0f && mat.shininess <= 1.0e6f) || !lightFinite;
+    if ((flags & kCfgSpecular) && __ballot(specularCounts) != 0ull) {
         if (flags & kCfgAreaSpecular) {
             const int softNum = P.softNum;
             const float softRadius = P.softRadius;
