@@ -454,7 +454,7 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
     auto& A = ctx->sceneAllocs;
     if ((rc = uploadArray(flat.sphGeom, &d.sphGeom, A, bytes)) || (rc = uploadArray(flat.sphMat, &d.sphMat, A, bytes)) ||
         (rc = uploadArray(flat.plnP, &d.plnP, A, bytes)) || (rc = uploadArray(flat.plnN, &d.plnN, A, bytes)) ||
-        (rc = uploadArray(flat.plnMat, &d.plnMat, A, bytes)) || (rc = uploadArray(flat.boxMin, &d.boxMin, A, bytes)) ||
+        (rc = uploadArray(flat.plnMat, &d.plnMat, A, bytes)) || (rc = uploadArray(flat.plnNormals, &d.plnNormals, A, bytes)) || (rc = uploadArray(flat.boxMin, &d.boxMin, A, bytes)) ||
         (rc = uploadArray(flat.boxMax, &d.boxMax, A, bytes)) || (rc = uploadArray(flat.boxMat, &d.boxMat, A, bytes)) ||
         (rc = uploadArray(flat.mdlGateMin, &d.mdlGateMin, A, bytes)) || (rc = uploadArray(flat.mdlGateMax, &d.mdlGateMax, A, bytes)) ||
         (rc = uploadArray(flat.mdlTightMin, &d.mdlTightMin, A, bytes)) || (rc = uploadArray(flat.mdlTightMax, &d.mdlTightMax, A, bytes)) ||
@@ -876,7 +876,7 @@ int rt_validate_scene_host(const rt_scene_desc* scene, rt_scene_info* info) {
         info->sphereCount = scene->sphereCount; info->planeCount = scene->planeCount; info->AABBCount = scene->AABBCount;
         info->modelCount = scene->modelCount; info->triangleCount = flat.triangleCount; info->nodeCount = flat.nodeCount;
         info->leafCount = flat.leafCount; info->maxDepth = flat.maxDepth;
-        info->deviceBytes = (int64_t)((flat.sphGeom.size() + flat.sphMat.size() + flat.plnP.size() + flat.plnN.size() + flat.plnMat.size() +
+        info->deviceBytes = (int64_t)((flat.sphGeom.size() + flat.sphMat.size() + flat.plnP.size() + flat.plnN.size() + flat.plnMat.size() + flat.plnNormals.size() +
                                        flat.boxMin.size() + flat.boxMax.size() + flat.boxMat.size() + flat.mdlGateMin.size() +
                                        flat.mdlGateMax.size() + flat.mdlTightMin.size() + flat.mdlTightMax.size() + flat.mdlMat.size() +
                                        flat.nodes.size() + flat.tris.size() + flat.attrs.size()) * sizeof(rt::F4) +

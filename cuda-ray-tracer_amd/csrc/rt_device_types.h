@@ -67,6 +67,10 @@ struct DevScene {
     const F4* plnP;
     const F4* plnN;
     const F4* plnMat;
+    // five per plane: -n, and -n normalised once, twice, three and four times (what the reference holds as the hit normal after
+    // one to three of its trace routines, and what it hands to the lighting after one more normalisation) - the same for every
+    // pixel of a plane, so the host works them out once with the kernel's arithmetic
+    const F4* plnNormals;
     // boxes
     const F4* boxMin;
     const F4* boxMax;

@@ -848,16 +848,23 @@ struct Surface {
 // Rebuilds hit point, normal and material of `h`.  `renorm` = how many trace routines of the reference run from
 // the winning object's own routine to the last one: each of them normalises the stored normal once more
 // (kernels.cu:90-93, 122-125).
+// A plane's normal is the same for all of its pixels: it is looked up (DevScene::plnNormals), and with it `lightNormal`, the
+// normal once more normalised, as the lighting takes it (kernels.cu:240-245); for every other kind of object the caller
+// normalises per pixel.
 template <bool STATS>
-RT_DEV Surface resolveSurface(SceneK& S, V3 o, V3 d, const Closest& h, int renorm, Counters& cnt) {
+RT_DEV Surface resolveSurface(SceneK& S, V3 o, V3 d, const Closest& h, int renorm, Counters& cnt, V3& lightNormal) {
     Surface s;
     s.point = o + d * h.t;
+    if (h.kind == KIND_PLANE) {
+        s.mat = loadMat(inGlobal(S.plnMat), h.idx);
+        const F4* const normals = inGlobal(S.plnNormals) + 5 * h.idx + renorm;
+        s.normal = xyz(ld4(normals));
+        lightNormal = xyz(ld4(normals + 1));
+        return s;
+    }
     if (h.kind == KIND_SPHERE) {
         s.mat = loadMat(inGlobal(S.sphMat), h.idx);
         s.normal = s.point - xyz(ld4(inGlobal(S.sphGeom) + h.idx));
-    } else if (h.kind == KIND_PLANE) {
-        s.mat = loadMat(inGlobal(S.plnMat), h.idx);
-        s.normal = neg(xyz(ld4(inGlobal(S.plnN) + h.idx)));
     } else if (h.kind == KIND_BOX) {
         s.mat = loadMat(inGlobal(S.boxMat), h.idx);
         s.normal = boxNormalAt(xyz(ld4(inGlobal(S.boxMin) + h.idx)), xyz(ld4(inGlobal(S.boxMax) + h.idx)), s.point);
@@ -934,12 +941,16 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
         V3 biased = mk(0, 0, 0), toLight = mk(0, 0, 1), point = mk(0, 0, 0), normal = mk(0, 0, 1);
         if (active && h.kind != KIND_NONE) {
             SectionTimer<STATS> tmShade;
-            Surface s = resolveSurface<STATS>(S, ro, rdir, h, renormCount(h.kind, planesRun, boxesRun, modelsRun), cnt);
+            V3 lightNormal = mk(0, 0, 1);
+            Surface s = resolveSurface<STATS>(S, ro, rdir, h, renormCount(h.kind, planesRun, boxesRun, modelsRun), cnt, lightNormal);
             const bool isDebug = (s.mat.flags & 1u) != 0;
             if (level == 0 && isDebug) {
                 colour = s.mat.ka;                                          // kernels.cu:309-312
             } else {
-                V3 nLight = (level == 0 && h.kind == KIND_BOX) ? s.normal : normalise(s.normal);   // kernels.cu:240-245
+                V3 nLight;                                                  // kernels.cu:240-245
+                if (level == 0 && h.kind == KIND_BOX) nLight = s.normal;
+                else if (h.kind == KIND_PLANE) nLight = lightNormal;
+                else nLight = normalise(s.normal);
                 const V3 lightPos = mk(S.lightPos);
                 colour = lighting(s.mat, lightPos, mk(S.lightCol), s.point, mk(cam + 13), nLight, P, px, py);
                 lit = true;

@@ -717,6 +717,16 @@ bool flattenScene(const rt_scene_desc& s, FlatScene& out, std::string& err, bool
         const rt_plane& o = s.planes[i];
         out.plnP.push_back(f4(o.position, 0.0f));
         out.plnN.push_back(f4(o.n, 0.0f));
+        {   // Plane.cpp:24 (normal = -n), then kernels.cu:90-93 once per trace routine and kernels.cu:240 before the lighting:
+            // normalise = v / sqrt((x x + y y) + z z), IEEE float without contraction, as the kernel evaluates it
+            float v[3] = {-o.n.x, -o.n.y, -o.n.z};
+            out.plnNormals.push_back(F4{v[0], v[1], v[2], 0.0f});
+            for (int k = 0; k < 4; k++) {
+                const float len = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+                v[0] = v[0] / len; v[1] = v[1] / len; v[2] = v[2] / len;
+                out.plnNormals.push_back(F4{v[0], v[1], v[2], 0.0f});
+            }
+        }
         packMaterial(o.mat, o.objectType, (o.debug ? 1u : 0u) | (isIgnoredPosition(o.position) ? 2u : 0u), mat);
         out.plnMat.insert(out.plnMat.end(), mat, mat + 3);
     }

@@ -31,7 +31,7 @@ struct DeviceBuildModel {
 
 // Host staging copy of everything that goes to HBM.
 struct FlatScene {
-    std::vector<F4> sphGeom, sphMat, plnP, plnN, plnMat, boxMin, boxMax, boxMat;
+    std::vector<F4> sphGeom, sphMat, plnP, plnN, plnMat, plnNormals, boxMin, boxMax, boxMat;
     std::vector<F4> mdlGateMin, mdlGateMax, mdlTightMin, mdlTightMax, mdlMat, mdlChunkMin, mdlChunkMax;
     bool chunksSequential = true;   // every model's chunk boxes list its triangles in file order (needed by the eight-box mode)
     std::vector<uint32_t> mdlInfo;
