@@ -33,7 +33,10 @@ constexpr uint32_t kNoRoot = 0xFFFFFFFFu;     // model without triangles / scene
 constexpr uint32_t kNoModel = 0xFFFFFFFFu;
 constexpr int kMaxOctreeDepth = 16;           // nesting levels (forest + model octree); the traversal keeps pool entries in reserve for a depth-first descent of this many levels
 constexpr int kMaxModelOctreeDepth = 10;      // cap on the per-model build depth
-constexpr int kPregatedModels = 64;           // up to this many models the gates are evaluated once per ray, up front
+#ifndef RT_PREGATED_MODELS
+#define RT_PREGATED_MODELS 64
+#endif
+constexpr int kPregatedModels = RT_PREGATED_MODELS;           // up to this many models the gates are evaluated once per ray, up front
 
 // ---- triangles ----
 // Leaf-ordered, 3 float4 per triangle: { v0.xyz, bits(id) }, { e1.xyz, bits(model) }, { e2.xyz, 0 } with e1 = v1 - v0 and

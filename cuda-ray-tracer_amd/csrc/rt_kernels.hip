@@ -360,12 +360,15 @@ RT_DEV uint32_t testChildren(u4_t head, u4_t qx, u4_t qy, u4_t qz, const SlabRay
     return lo4 | (hi4 << 4);
 }
 
-RT_DEV bool tightBoxHit(V3 lo, V3 hi, const SlabRay& r, float tmin, float tmax) {
-    float ax = (lo.x - r.o.x) * r.rd.x, bx = (hi.x - r.o.x) * r.rd.x;
-    float ay = (lo.y - r.o.y) * r.rd.y, by = (hi.y - r.o.y) * r.rd.y;
+// (x and y of a corner go through one packed subtraction and one packed multiplication: the corner arrives in a pair of scalar
+// registers, origin and reciprocal direction lie in register pairs)
+RT_DEV bool tightBoxHit(f4_t lo, f4_t hi, const SlabRay& r, float tmin, float tmax) {
+    const f2_t oxy = {r.o.x, r.o.y}, rxy = {r.rd.x, r.rd.y};
+    const f2_t loxy = {lo.x, lo.y}, hixy = {hi.x, hi.y};
+    const f2_t a = (loxy - oxy) * rxy, b = (hixy - oxy) * rxy;
     float az = (lo.z - r.o.z) * r.rd.z, bz = (hi.z - r.o.z) * r.rd.z;
-    float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    float tn = fmaxf(fmaxf(fminf(a.x, b.x), fminf(a.y, b.y)), fmaxf(fminf(az, bz), tmin));
+    float tf = fminf(fminf(fmaxf(a.x, b.x), fmaxf(a.y, b.y)), fminf(fmaxf(az, bz), tmax));
     return tn <= tf;
 }
 
@@ -443,8 +446,10 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
         const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
         const F4* const tightMin = inGlobal(S.mdlTightMin), * const tightMax = inGlobal(S.mdlTightMax);
         const F4* const mdlMat = inGlobal(S.mdlMat), * const gateMin = inGlobal(S.mdlGateMin), * const gateMax = inGlobal(S.mdlGateMax);
+        // (quieted once here: the minimum / maximum instructions would otherwise do it for these two operands in every round)
+        const float tminGate = __builtin_canonicalizef(tmin), tmaxGate = __builtin_canonicalizef(startT);
         for (int j = 0; j < nMdl; j++) {
-            if (!tightBoxHit(xyz(ldu4(tightMin + j)), xyz(ldu4(tightMax + j)), sr, tmin, startT)) continue;
+            if (!tightBoxHit(ldu4(tightMin + j), ldu4(tightMax + j), sr, tminGate, tmaxGate)) continue;
             if (gate(mdlMat, gateMin, gateMax, j, o, d, sr.rd, fin, true)) gateBits |= 1ull << j;
         }
         timerG.stop(lds, 2);
