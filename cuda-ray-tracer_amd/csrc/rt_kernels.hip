@@ -351,8 +351,12 @@ RT_DEV uint32_t testFour(uint32_t nx, uint32_t ny, uint32_t nz, uint32_t fx, uin
 // origin and the node - under 3e-7 of that distance on the plane's axis, and a hit that counts is nearer than 999.
 RT_DEV uint32_t testChildren(u4_t head, u4_t qx, u4_t qy, u4_t qz, const SlabRay& r, float tmin, float tmax) {
     // plane at origin + q * step  ->  parameter (origin + q * step - o) / d = q * (step * rd) + (origin - o) * rd
-    const V3 s = mk(ubits((head.w & 0xffu) << 23) * r.rd.x, ubits(((head.w >> 8) & 0xffu) << 23) * r.rd.y, ubits(((head.w >> 16) & 0xffu) << 23) * r.rd.z);
-    const V3 b = mk((ubits(head.x) - r.o.x) * r.rd.x, (ubits(head.y) - r.o.y) * r.rd.y, (ubits(head.z) - r.o.z) * r.rd.z);
+    // (x and y in packed instructions: origin, reciprocal direction and the node's origin each lie in a register pair)
+    const f2_t rdxy = {r.rd.x, r.rd.y}, oxy = {r.o.x, r.o.y};
+    const f2_t stepxy = {ubits((head.w & 0xffu) << 23), ubits(((head.w >> 8) & 0xffu) << 23)}, nodexy = {ubits(head.x), ubits(head.y)};
+    const f2_t sxy = stepxy * rdxy, bxy = (nodexy - oxy) * rdxy;
+    const V3 s = mk(sxy.x, sxy.y, ubits(((head.w >> 16) & 0xffu) << 23) * r.rd.z);
+    const V3 b = mk(bxy.x, bxy.y, (ubits(head.z) - r.o.z) * r.rd.z);
     // the ray enters through the low planes on axes it travels along in the positive direction, the high planes otherwise
     const bool px = !(r.oct & 1u), py = !(r.oct & 2u), pz = !(r.oct & 4u);
     uint32_t lo4 = testFour(px ? qx.x : qx.z, py ? qy.x : qy.z, pz ? qz.x : qz.z, px ? qx.z : qx.x, py ? qy.z : qy.x, pz ? qz.z : qz.x, s, b, tmin, tmax);
@@ -440,9 +444,10 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
     // gate would otherwise be met by single lanes at model roots).  The cheap conservative test of the triangles' own box
     // comes first; the order does not change the result.  Larger scenes evaluate a gate when an entry reaches a model root.
     unsigned long long gateBits = 0;
+    const SlabRay own = makeSlabRay(o, d);
     if (hasRay && pregated) {
         SectionTimer<STATS> timerG;
-        const SlabRay sr = makeSlabRay(o, d);
+        const SlabRay& sr = own;
         const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
         const F4* const tightMin = inGlobal(S.mdlTightMin), * const tightMax = inGlobal(S.mdlTightMax);
         const F4* const mdlMat = inGlobal(S.mdlMat), * const gateMin = inGlobal(S.mdlGateMin), * const gateMax = inGlobal(S.mdlGateMax);
@@ -456,7 +461,6 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
     }
     const bool enters = hasRay && (!pregated || gateBits != 0);
     if (__ballot(enters) == 0ull) { timerWhole.stop(lds, 3); return false; }     // no ray of this wave comes near a mesh
-    const SlabRay own = makeSlabRay(o, d);
     {
         f4_t ro4 = {o.x, o.y, o.z, ubits((uint32_t)gateBits)}, rd4 = {d.x, d.y, d.z, ubits((uint32_t)(gateBits >> 32))};
         f4_t rr4 = {own.rd.x, own.rd.y, own.rd.z, ubits(own.oct)};
