@@ -81,8 +81,8 @@ struct DevScene {
     // models: gate box (exact reference semantics), tight box of the triangles, material, info
     const F4* mdlGateMin;
     const F4* mdlGateMax;
-    const F4* mdlTightMin;
-    const F4* mdlTightMax;
+    const F4* mdlTightMin;     // w: a ray that meets the tight box and whose largest origin coordinate is at most this passes the gate
+    const F4* mdlTightMax;     //    (the gate box surrounds the tight box by a margin that outweighs the rounding of both tests; -inf: never)
     const F4* mdlMat;          // same 3-float4 material layout
     const F4* mdlChunkMin;     // 8 per model: the eight sequential-chunk boxes (eight-box mesh mode)
     const F4* mdlChunkMax;

@@ -428,10 +428,13 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
     // Is model mm a candidate for the ray at all: not hidden from this ray type, and (whole-box mode) through the
     // reference's exact bounding-box gate.
     // (uniform: mm is the same for the whole wave)
-    auto gate = [&](const F4* mdlMat, const F4* gateMin, const F4* gateMax, int mm, V3 ro, V3 rdir, V3 rrd, bool fin, const bool uniform) -> bool {
+    // (implied: the ray met the model's tight box and starts within the range in which that settles the gate, see the w word
+    // of DevScene::mdlTightMin)
+    auto gate = [&](const F4* mdlMat, const F4* gateMin, const F4* gateMax, int mm, V3 ro, V3 rdir, V3 rrd, bool fin, const bool uniform, bool implied) -> bool {
         if ((skipDebug || ANYHIT) && ((uniform ? lduFlags(mdlMat + 3 * mm + 2) : fbits(mdlMat[3 * mm + 2].w)) & 1u)) return false;
         if (meshMode == kMeshWholeBox) {
             if (STATS) cnt.gateTests++;
+            if (implied && fin) return true;
             const f4_t lo = uniform ? ldu4(gateMin + mm) : ld4(gateMin + mm), hi = uniform ? ldu4(gateMax + mm) : ld4(gateMax + mm);
             return boxHitDecision(xyz(lo), xyz(hi), ro, rdir, rrd, fin);
         }
@@ -453,9 +456,11 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
         const F4* const mdlMat = inGlobal(S.mdlMat), * const gateMin = inGlobal(S.mdlGateMin), * const gateMax = inGlobal(S.mdlGateMax);
         // (quieted once here: the minimum / maximum instructions would otherwise do it for these two operands in every round)
         const float tminGate = __builtin_canonicalizef(tmin), tmaxGate = __builtin_canonicalizef(startT);
+        const float originReach = fmaxf(fmaxf(fabsf(o.x), fabsf(o.y)), fabsf(o.z));
         for (int j = 0; j < nMdl; j++) {
-            if (!tightBoxHit(ldu4(tightMin + j), ldu4(tightMax + j), sr, tminGate, tmaxGate)) continue;
-            if (gate(mdlMat, gateMin, gateMax, j, o, d, sr.rd, fin, true)) gateBits |= 1ull << j;
+            const f4_t tightLo = ldu4(tightMin + j);
+            if (!tightBoxHit(tightLo, ldu4(tightMax + j), sr, tminGate, tmaxGate)) continue;
+            if (gate(mdlMat, gateMin, gateMax, j, o, d, sr.rd, fin, true, originReach <= tightLo.w)) gateBits |= 1ull << j;
         }
         timerG.stop(lds, 2);
     }
@@ -561,7 +566,7 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
                     const V3 rdir = xyz(rd4);
                     const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
                     const unsigned long long bits = (unsigned long long)fbits(ro4.w) | ((unsigned long long)fbits(rd4.w) << 32);
-                    bool enter = pregated ? (((bits >> mm) & 1ull) != 0) : gate(inGlobal(S.mdlMat), inGlobal(S.mdlGateMin), inGlobal(S.mdlGateMax), mm, ro, rdir, sr.rd, fin, false);
+                    bool enter = pregated ? (((bits >> mm) & 1ull) != 0) : gate(inGlobal(S.mdlMat), inGlobal(S.mdlGateMin), inGlobal(S.mdlGateMax), mm, ro, rdir, sr.rd, fin, false, false);
                     if (enter && meshMode == kMeshEightBoxes) {      // Model.cpp:225-227: each chunk of triangles has its own exact gate
                         chunkMask = 0;
                         const F4* const chunkMin = inGlobal(S.mdlChunkMin), * const chunkMax = inGlobal(S.mdlChunkMax);
@@ -813,9 +818,10 @@ RT_DEV bool shadowBoxes(SceneK& S, V3 o, V3 d) {
 
 // v = normalise(cameraPosition) (kernels.cu:20-65 evaluates it per pixel; it is the same for the whole frame and arrives in
 // the frame parameters, computed on the host with the same three divisions and square root).
-RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 v, V3 normal, FrameK& P, int px, int py) {
+// L = normalise(lightPos - point), which the caller also needs as the direction of the hard shadow ray (kernels.cu:22 and :269
+// evaluate the same expression).
+RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 L, V3 v, V3 normal, FrameK& P, int px, int py) {
     V3 colour = mk(0, 0, 0);
-    V3 L = normalise(lightPos - point);
     const uint32_t flags = P.flags;
     if (flags & kCfgAmbient) colour = (lightCol * mat.ka) * mat.ambient;
     if (flags & kCfgDiffuse) {
@@ -961,11 +967,11 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
                 else if (h.kind == KIND_PLANE) nLight = lightNormal;
                 else nLight = normalise(s.normal);
                 const V3 lightPos = mk(S.lightPos);
-                colour = lighting(s.mat, lightPos, mk(S.lightCol), s.point, mk(cam + 13), nLight, P, px, py);
+                toLight = normalise(lightPos - s.point);
+                colour = lighting(s.mat, lightPos, mk(S.lightCol), s.point, toLight, mk(cam + 13), nLight, P, px, py);
                 lit = true;
                 point = s.point; normal = s.normal;
                 biased = s.point + s.normal * P.shadowBias;
-                toLight = normalise(lightPos - s.point);
                 if (level == 0) wantNext = reflections && s.mat.type == 1u && !(h.kind == KIND_PLANE && !reflectPlanes);
                 else wantNext = reflections && s.mat.type == 1u && (1 < P.maxDepth) && level < 3;
                 if (wantNext) {

@@ -605,7 +605,24 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
     out.mdlGateMin.push_back(f4(m.bbMin, 0.0f));
     out.mdlGateMax.push_back(f4(m.bbMax, 0.0f));
     if (nTri > 0) {
-        out.mdlTightMin.push_back(f4(tight.lo[0] - pad, tight.lo[1] - pad, tight.lo[2] - pad, 0.0f));
+        // When does a ray that meets the tight box also pass the reference's gate (AABB::hit on the model's own box, which holds
+        // the world origin and is padded by 0.1 wherever a vertex extended it)?  If the gate box surrounds the tight box by a
+        // margin m on every side, a ray found to meet the tight box within [0, tmax] has a point at a parameter >= 0 that lies
+        // inside the gate box by nearly m on every axis, so each of the gate's three parameter intervals contains that
+        // parameter with a slack of m / |d_a|, while the gate's six quotients carry an error below 2e-7 D / |d_a| (D = the
+        // largest distance between the ray origin and a gate plane along an axis) - and the tight test itself less than 1e-6 D
+        // in position.  With m >= 8e-6 D every comparison of AABB::hit is decided with room to spare and the gate accepts the
+        // ray; D <= (largest gate coordinate) + (largest origin coordinate), so the kernel needs one comparison of the
+        // latter with the limit below to know the gate's answer without evaluating it (finite reciprocal directions only).
+        float margin = std::numeric_limits<float>::infinity(), gateAbs = 0.0f;
+        const float bbLo[3] = {m.bbMin.x, m.bbMin.y, m.bbMin.z}, bbHi[3] = {m.bbMax.x, m.bbMax.y, m.bbMax.z};
+        for (int a = 0; a < 3; a++) {
+            margin = std::min(margin, std::min((tight.lo[a] - pad) - bbLo[a], bbHi[a] - (tight.hi[a] + pad)));
+            gateAbs = std::max(gateAbs, std::max(std::fabs(bbLo[a]), std::fabs(bbHi[a])));
+        }
+        const float impliedLimit = (margin > 0.0f && std::isfinite(margin) && std::isfinite(gateAbs)) ? margin / 8e-6f - gateAbs
+                                                                                                   : -std::numeric_limits<float>::infinity();
+        out.mdlTightMin.push_back(f4(tight.lo[0] - pad, tight.lo[1] - pad, tight.lo[2] - pad, impliedLimit));
         out.mdlTightMax.push_back(f4(tight.hi[0] + pad, tight.hi[1] + pad, tight.hi[2] + pad, 0.0f));
     } else {
         const float inf = std::numeric_limits<float>::infinity();
