@@ -44,7 +44,10 @@ constexpr uint32_t kSplitGainNum = 5, kSplitGainDen = 3;   // a block rendered b
 #define RT_RCP_IN_LDS 1
 #endif
 constexpr int kNodePool = RT_NODE_POOL_ENTRIES;       // mesh traversal: entries of pending children per wave
-constexpr int kTriPool = 288;        // and of pending triangle work: runs of triangles, and sets of leaves of one node
+#ifndef RT_TRI_POOL_ENTRIES
+#define RT_TRI_POOL_ENTRIES 288
+#endif
+constexpr int kTriPool = RT_TRI_POOL_ENTRIES;        // and of pending triangle work: runs of triangles, and sets of leaves of one node
 constexpr uint32_t kNodeIndexBits = 29, kNodeIndexMask = (1u << kNodeIndexBits) - 1u;   // node pool entry, low word: first child | octant << 29
 constexpr uint32_t kLeafSet = 1u << 27;   // triangle pool entry, high word: owner | chunks << 8 | (leaf set: hit mask << 16 | octant << 24 | kLeafSet)
 // Triangle turns are taken once this many entries are pending (1080p benchmark frame: 24 -> +8 %, 40 -> +2 %, 52 .. 58 within
