@@ -22,7 +22,9 @@ def random_material(rng):
     return (ka, kd, float(rng.uniform(0.05, 0.4)), float(rng.uniform(0.3, 0.9)), float(rng.uniform(0.0, 1.0)), float(rng.choice([5.0, 50.0, 200.0, 1000.0])))
 
 
-def random_scene(seed):
+def random_scene(seed, variety=False):
+    """variety: also tilted planes with normals that are not unit vectors, materials without a specular part, more debug
+    objects (the conditions of the kernel's short cuts); the scenes of variety=False stay what they were."""
     rng = np.random.default_rng(seed)
     kinds = (T.RT_DIFFUSE, T.RT_REFLECT)
     spec = scenes.SceneSpec()
@@ -41,6 +43,21 @@ def random_scene(seed):
         pos = tuple(float(v) for v in rng.uniform((-35, 8, -35), (35, 20, 35)))
         spec.models.append(scenes.ModelSpec(name, pos, int(rng.integers(8, 30)), random_material(rng), bool(rng.random() < 0.15),
                                             int(rng.choice(kinds)), float(rng.choice([0.1, 0.2, 0.3]))))
+    if variety:
+        vr = np.random.default_rng(seed + 0x5EED)
+        def dull(mat):
+            return mat[:4] + (0.0, float(vr.choice([0.0, 10.0, 200.0, -3.0])))
+        if vr.random() < 0.4:
+            n = tuple(float(v) for v in vr.uniform((-0.5, 0.6, -0.5), (0.5, 2.5, 0.5)))
+            spec.planes[0] = ((0.0, 20.0, 0.0), n, scenes.FLOOR if vr.random() < 0.5 else random_material(vr), int(vr.choice(kinds)))
+        if vr.random() < 0.5:
+            n = tuple(float(v) for v in vr.uniform((-3.0, -0.3, 0.2), (3.0, 0.6, 3.0)))
+            spec.planes.append(((float(vr.uniform(-60, 60)), 0.0, float(vr.uniform(-90, -40))), n, dull(random_material(vr)) if vr.random() < 0.5 else random_material(vr), int(vr.choice(kinds))))
+        spec.spheres = [sp if vr.random() < 0.6 else (sp[0], sp[1], dull(sp[2]), sp[3], sp[4]) for sp in spec.spheres[:1]] + \
+                       [sp if vr.random() < 0.6 else (sp[0], sp[1], dull(sp[2]), bool(vr.random() < 0.3), sp[4]) for sp in spec.spheres[1:]]
+        for m in spec.models:
+            if vr.random() < 0.4:
+                m.mat = dull(m.mat)
     spec.cam_pos = tuple(float(v) for v in rng.uniform((-60, -30, 30), (60, 5, 90)))
     spec.cam_yaw = float(rng.uniform(-120, -60)); spec.cam_pitch = float(rng.uniform(-5, 25)); spec.fov = float(rng.choice([60.0, 75.0, 90.0]))
     cfg = scenes.default_config()

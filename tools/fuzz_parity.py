@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Differential campaign on the GPU box: seeded random scenes (the generator of tests/test_gpu_random_scenes.py) rendered by
 the library and by the CPU oracle; prints every seed that misses the parity bar and a summary.
-Usage: python tools/fuzz_parity.py <first seed> <count> [width height]"""
+Usage: python tools/fuzz_parity.py <first seed> <count> [width height [variety]]"""
 import os
 import sys
 
@@ -19,11 +19,12 @@ from test_gpu_random_scenes import random_scene  # noqa: E402
 
 first, count = int(sys.argv[1]), int(sys.argv[2])
 w, h = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (224, 126)
+VARIETY = len(sys.argv) > 5 and sys.argv[5] == "variety"      # tilted planes, materials without a specular part, more debug objects
 r = binding.Renderer(0)
 O = oracle_lib.Oracle()
 bad = 0; lsb = 0; total_px = 0; mesh_px = 0
 for seed in range(first, first + count):
-    spec, cfg = random_scene(seed)
+    spec, cfg = random_scene(seed, variety=VARIETY)
     built = scenes.build_scene(spec, build_on_device=bool(seed % 3 == 2))
     r.upload(built.desc); r.set_state(built.camera, cfg)
     g_rgb, g_ids, g_t, st = r.render_ids(w, h)
