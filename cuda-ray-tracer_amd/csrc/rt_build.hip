@@ -337,7 +337,7 @@ __global__ __launch_bounds__(256) void emitTrianglesKernel(const BuildModelDev* 
     const uint32_t id = t | chunkTagOf((int64_t)t, (int64_t)M.perBoxTris, M.chunkIndices) | (lastFlag[p] ? kTriLast : 0u);
     tris[3 * (size_t)p + 0] = F4{p0.x, p0.y, p0.z, codecBitsToFloat(id)};
     tris[3 * (size_t)p + 1] = F4{p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, codecBitsToFloat((uint32_t)M.model)};   // Model.cpp:137
-    tris[3 * (size_t)p + 2] = F4{p2.x - p0.x, p2.y - p0.y, p2.z - p0.z, 0.0f};                                  // Model.cpp:138
+    tris[3 * (size_t)p + 2] = F4{p2.x - p0.x, p2.y - p0.y, p2.z - p0.z, codecBitsToFloat(M.triStart)};          // Model.cpp:138
 }
 
 __global__ __launch_bounds__(256) void emitAttributesKernel(const BuildModelDev* __restrict__ models, int modelCount, uint32_t total,

@@ -39,7 +39,7 @@ constexpr int kMaxModelOctreeDepth = 10;      // cap on the per-model build dept
 constexpr int kPregatedModels = RT_PREGATED_MODELS;           // up to this many models the gates are evaluated once per ray, up front
 
 // ---- triangles ----
-// Leaf-ordered, 3 float4 per triangle: { v0.xyz, bits(id) }, { e1.xyz, bits(model) }, { e2.xyz, 0 } with e1 = v1 - v0 and
+// Leaf-ordered, 3 float4 per triangle: { v0.xyz, bits(id) }, { e1.xyz, bits(model) }, { e2.xyz, bits(attribute base of the model) } with e1 = v1 - v0 and
 // e2 = v2 - v0 computed in float on the host (the same subtraction the intersection routine starts with).
 // The id word: bits 0-26 triangle index inside its model, bits 27-29 which of the model's eight sequential chunk boxes
 // the triangle belongs to, bit 30 set if it sits in the last slot of its chunk (which the eight-box mesh mode never

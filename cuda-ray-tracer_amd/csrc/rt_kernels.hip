@@ -693,8 +693,8 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
                         if (t < FAR_T) lds.bestKey[owner] = 0ull;
                         return;
                     }
-                    const int mm = (int)fbits(B.w);
-                    const uint32_t key = mdlInfo[4 * mm + 1] + (idw & kTriIdMask);
+                    // (the third record carries the model's first position in the attribute array)
+                    const uint32_t key = fbits(C.w) + (idw & kTriIdMask);
                     const unsigned long long cand = ((unsigned long long)orderBits(t + 0.0f) << 32) | key;    // -0 orders as +0
                     if (cand < bk) {
                         atomicMin(&lds.bestKey[owner], cand);

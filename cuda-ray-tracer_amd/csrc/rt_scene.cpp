@@ -511,7 +511,7 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
             uint32_t id = (uint32_t)ids[i] | chunkTag[(size_t)ids[i]] | (i + 1 == ids.size() ? kTriLast : 0u);
             out.tris.push_back(f4(p0.x, p0.y, p0.z, bitsFloat(id)));
             out.tris.push_back(f4(p1.x - p0.x, p1.y - p0.y, p1.z - p0.z, bitsFloat((uint32_t)modelIndex)));   // Model.cpp:137
-            out.tris.push_back(f4(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z, 0.0f));   // Model.cpp:138
+            out.tris.push_back(f4(p2.x - p0.x, p2.y - p0.y, p2.z - p0.z, bitsFloat(triBase)));   // Model.cpp:138
         }
         out.leafCount++;
         return start;
@@ -591,6 +591,7 @@ static bool flattenModel(const rt_model& m, int modelIndex, const OctreeParams& 
         for (int64_t t = 0; t < nTri; t++) {
             F4 a = tsrc[3 * t], b = tsrc[3 * t + 1], c = tsrc[3 * t + 2];
             b.w = bitsFloat((uint32_t)modelIndex);
+            c.w = bitsFloat(triBase);
             out.tris.push_back(a); out.tris.push_back(b); out.tris.push_back(c);
         }
         out.leafCount += pre->leafCount;
