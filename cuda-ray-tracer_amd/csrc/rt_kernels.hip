@@ -247,7 +247,7 @@ enum { KIND_NONE = -1, KIND_SPHERE = 0, KIND_PLANE = 1, KIND_MODEL = 4, KIND_BOX
 struct Closest {
     float t;      // FAR_T = nothing yet
     int kind, idx;
-    int tri;      // triangle id inside model idx (model hits)
+    int tri;      // model hits: the triangle's position in the scene-wide attribute array (the model's base + its index in the model)
     float u, v;
 };
 
@@ -737,7 +737,7 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
             V3 qvec = cross(tvec, e1);
             float v = dot(d, qvec) * invDet;
             float t = dot(e2, qvec) * invDet;
-            best.t = t; best.kind = KIND_MODEL; best.idx = (int)fbits(B.w); best.tri = (int)(fbits(A.w) & kTriIdMask); best.u = u; best.v = v;
+            best.t = t; best.kind = KIND_MODEL; best.idx = (int)fbits(B.w); best.tri = (int)(fbits(C.w) + (fbits(A.w) & kTriIdMask)); best.u = u; best.v = v;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -888,8 +888,7 @@ RT_DEV Surface resolveSurface(SceneK& S, V3 o, V3 d, const Closest& h, int renor
         s.normal = boxNormalAt(xyz(ld4(inGlobal(S.boxMin) + h.idx)), xyz(ld4(inGlobal(S.boxMax) + h.idx)), s.point);
     } else {
         s.mat = loadMat(inGlobal(S.mdlMat), h.idx);
-        uint32_t triBase = inGlobal(S.mdlInfo)[4 * h.idx + 1];
-        const F4* ap = inGlobal(S.attrs) + (size_t)(triBase + (uint32_t)h.tri) * kAttrFloat4s;
+        const F4* ap = inGlobal(S.attrs) + (size_t)(uint32_t)h.tri * kAttrFloat4s;
         f4_t a0 = ld4(ap), a1 = ld4(ap + 1), a2 = ld4(ap + 2), a3 = ld4(ap + 3), a4 = ld4(ap + 4), a5 = ld4(ap + 5), a6 = ld4(ap + 6);
         if (STATS) cnt.attrFetches++;
         float u = h.u, v = h.v, w = 1 - u - v;
@@ -1256,7 +1255,10 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
                 size_t fp = (size_t)y * (size_t)P.width + (size_t)x;
                 bool hit = primary.kind != KIND_NONE;
                 ids[fp * 2 + 0] = hit ? ((primary.kind << 24) | (primary.idx & 0xFFFFFF)) : -1;
-                ids[fp * 2 + 1] = hit ? primary.tri : -1;
+                // (a model hit holds its position in the scene-wide attribute array; the caller gets the triangle's index in its model)
+                int triId = primary.tri;
+                if (hit && primary.kind == KIND_MODEL) triId -= (int)inGlobal(S.mdlInfo)[4 * primary.idx + 1];
+                ids[fp * 2 + 1] = hit ? triId : -1;
                 if (tbuf) tbuf[fp] = primary.t;
             } else if (tbuf) {
                 tbuf[(size_t)y * (size_t)P.width + (size_t)x] = primary.t;
