@@ -329,6 +329,7 @@ int renderToHost(rt_ctx* ctx, int width, int height, uint8_t* rgbOut, int32_t* i
         stats->attr_fetches = counters[rt::kCntAttrFetches];
         stats->gate_tests = counters[rt::kCntGateTests];
         stats->node_visits = counters[rt::kCntNodeVisits];
+        stats->table_flops = counters[rt::kCntTableFlops];
         stats->split_waves = ctx->hSplitWaves ? *ctx->hSplitWaves : 0u;
     }
     return RT_OK;

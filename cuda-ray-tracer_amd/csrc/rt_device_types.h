@@ -164,7 +164,7 @@ struct SplitState {
 // Per-launch counters (one 64-bit word each), accumulated with one atomic per wave.  The buffer holds kCounterSlots sets of
 // them, one cache line apart; workgroup b adds to set b % kCounterSlots and the host adds the sets up.  (Thirty thousand
 // atomics on one address from eight XCDs take 0.26 ms, longer than the 1080p frame they count.)
-enum { kCntRays = 0, kCntNodeTests, kCntTriTests, kCntAttrFetches, kCntGateTests, kCntNodeVisits, kCntCount };
+enum { kCntRays = 0, kCntNodeTests, kCntTriTests, kCntAttrFetches, kCntGateTests, kCntNodeVisits, kCntTableFlops, kCntCount };
 constexpr int kCounterSlots = 256;
 constexpr int kCounterStride = 16;          // 64-bit words from one set to the next
 constexpr int kCounterWords = kCounterSlots * kCounterStride;

@@ -251,7 +251,7 @@ struct Closest {
     float u, v;
 };
 
-struct Counters { uint32_t rays, nodeTests, triTests, attrFetches, gateTests, nodeVisits; };
+struct Counters { uint32_t rays, nodeTests, triTests, attrFetches, gateTests, nodeVisits, tableFlops; };
 
 // The wave's working set in LDS for the mesh traversal (tracePool); everything is indexed by lane or by pool position.
 struct WaveLds {
@@ -436,8 +436,8 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
     auto gate = [&](const F4* mdlMat, const F4* gateMin, const F4* gateMax, int mm, V3 ro, V3 rdir, V3 rrd, bool fin, const bool uniform, bool implied) -> bool {
         if ((skipDebug || ANYHIT) && ((uniform ? lduFlags(mdlMat + 3 * mm + 2) : fbits(mdlMat[3 * mm + 2].w)) & 1u)) return false;
         if (meshMode == kMeshWholeBox) {
-            if (STATS) cnt.gateTests++;
             if (implied && fin) return true;
+            if (STATS) cnt.gateTests++;
             const f4_t lo = uniform ? ldu4(gateMin + mm) : ld4(gateMin + mm), hi = uniform ? ldu4(gateMax + mm) : ld4(gateMax + mm);
             return boxHitDecision(xyz(lo), xyz(hi), ro, rdir, rrd, fin);
         }
@@ -749,8 +749,10 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
 
 // kernels.cu:67-96 over the three analytic object tables, closest hit.  skipDebug* mirror the ray types the
 // reference uses for each table at this level.
+// flops (instrumented kernel only): 30 / 14 / 26 per sphere / plane / box test that is made.
+template <bool STATS>
 RT_DEV void traceAnalytic(SceneK& S, V3 o, V3 d, bool skipDebugSpheres, bool tracePlanes, bool skipDebugPlanes,
-                          bool traceBoxes, Closest& best) {
+                          bool traceBoxes, Closest& best, uint32_t& flops) {
     const int nSph = S.nSph;
     const F4* const sphGeom = inGlobal(S.sphGeom), * const sphMat = inGlobal(S.sphMat);
     for (int i = 0; i < nSph; i++) {
@@ -761,6 +763,7 @@ RT_DEV void traceAnalytic(SceneK& S, V3 o, V3 d, bool skipDebugSpheres, bool tra
         // effect, and the flags are the same for the whole wave, so the discarded tests are not made at all - the light's
         // marker sphere of every reference scene is such an object for every shadow and reflection ray)
         if (skipDebugSpheres && (flags & 1u)) continue;
+        if (STATS) flops += 30u;
         float t0;
         if (sphereHit(xyz(g), g.w, o, d, t0)) {
             if (t0 < best.t) { best.t = t0; best.kind = KIND_SPHERE; best.idx = i; }
@@ -773,6 +776,7 @@ RT_DEV void traceAnalytic(SceneK& S, V3 o, V3 d, bool skipDebugSpheres, bool tra
             uint32_t flags = lduFlags(plnMat + 3 * i + 2);
             if (flags & 2u) continue;
             if (skipDebugPlanes && (flags & 1u)) continue;
+            if (STATS) flops += 14u;
             float t0;
             if (planeHit(xyz(ldu4(plnP + i)), xyz(ldu4(plnN + i)), o, d, t0)) {
                 if (t0 < best.t) { best.t = t0; best.kind = KIND_PLANE; best.idx = i; }
@@ -784,6 +788,7 @@ RT_DEV void traceAnalytic(SceneK& S, V3 o, V3 d, bool skipDebugSpheres, bool tra
         const F4* const boxMin = inGlobal(S.boxMin), * const boxMax = inGlobal(S.boxMax), * const boxMat = inGlobal(S.boxMat);
         for (int i = 0; i < nBox; i++) {
             if (lduFlags(boxMat + 3 * i + 2) & 1u) continue;   // boxes are always traced as reflection rays (kernels.cu:228)
+            if (STATS) flops += 26u;
             float t0;
             if (boxHit(xyz(ldu4(boxMin + i)), xyz(ldu4(boxMax + i)), o, d, t0)) {
                 if (t0 < best.t) { best.t = t0; best.kind = KIND_BOX; best.idx = i; }
@@ -792,25 +797,29 @@ RT_DEV void traceAnalytic(SceneK& S, V3 o, V3 d, bool skipDebugSpheres, bool tra
     }
 }
 
-RT_DEV bool shadowSpheres(SceneK& S, V3 o, V3 d) {
+template <bool STATS>
+RT_DEV bool shadowSpheres(SceneK& S, V3 o, V3 d, uint32_t& flops) {
     const int nSph = S.nSph;
     const F4* const sphGeom = inGlobal(S.sphGeom), * const sphMat = inGlobal(S.sphMat);
     for (int i = 0; i < nSph; i++) {
         f4_t g = ldu4(sphGeom + i);
         uint32_t flags = lduFlags(sphMat + 3 * i + 2);
         if (flags & 3u) continue;       // hidden, or a debug object, which never casts a shadow (kernels.cu:78)
+        if (STATS) flops += 30u;
         float t0;
         if (sphereHit(xyz(g), g.w, o, d, t0)) return true;
     }
     return false;
 }
 
-RT_DEV bool shadowBoxes(SceneK& S, V3 o, V3 d) {
+template <bool STATS>
+RT_DEV bool shadowBoxes(SceneK& S, V3 o, V3 d, uint32_t& flops) {
     const int nBox = S.nBox;
     if (nBox == 0) return false;
     const F4* const boxMin = inGlobal(S.boxMin), * const boxMax = inGlobal(S.boxMax), * const boxMat = inGlobal(S.boxMat);
     for (int i = 0; i < nBox; i++) {
         if (lduFlags(boxMat + 3 * i + 2) & 1u) continue;
+        if (STATS) flops += 26u;
         float t0;
         if (boxHit(xyz(ldu4(boxMin + i)), xyz(ldu4(boxMax + i)), o, d, t0)) return true;
     }
@@ -947,7 +956,7 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
         if (active) {
             deepest = level;
             cnt.rays++;
-            SectionTimer<STATS> tm; traceAnalytic(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h); tm.stop(lds, 4);
+            SectionTimer<STATS> tm; traceAnalytic<STATS>(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h, cnt.tableFlops); tm.stop(lds, 4);
         }
         // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
         if (modelsVisible) tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, nodeCapacity, (uint32_t)P.traversal, h, lds, cnt);
@@ -1007,8 +1016,8 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
                     }
                     cnt.rays++;
                     SectionTimer<STATS> tmSh;
-                    bySphere = shadowSpheres(S, biased, sd);
-                    byBox = (hard && bySphere) ? false : shadowBoxes(S, biased, sd);
+                    bySphere = shadowSpheres<STATS>(S, biased, sd, cnt.tableFlops);
+                    byBox = (hard && bySphere) ? false : shadowBoxes<STATS>(S, biased, sd, cnt.tableFlops);
                     tmSh.stop(lds, 6);
                 }
                 bool byModel = false;
@@ -1028,7 +1037,7 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
             }
         } else if (hardShadows && lit) {
             cnt.rays++;
-            shadowed = shadowSpheres(S, biased, toLight);                                  // kernels.cu:142, 164, 214
+            shadowed = shadowSpheres<STATS>(S, biased, toLight, cnt.tableFlops);                                  // kernels.cu:142, 164, 214
         }
         if (lit) {
             if (level == 0) str0 = strength; else if (level == 1) str1 = strength; else if (level == 2) str2 = strength;
@@ -1218,7 +1227,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
     const uint32_t lx = bx + (lane & 7u), ly = by + (splitWave ? sub : (lane >> 3));
     const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
 
-    Counters cnt; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; cnt.nodeVisits = 0;
+    Counters cnt; cnt.tableFlops = 0; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; cnt.nodeVisits = 0;
     const bool inFrame = pixelLane && x < P.width && y < P.height;
     {      // all 64 lanes, also those without a pixel: the mesh trace is a wave-wide operation
         const V3 camPos = mk(cam);
@@ -1286,7 +1295,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
     // one atomic per wave and counter
     unsigned long long* counters = inGlobal(A.counters);
     if (counters) {
-        uint32_t vals[kCntCount] = {cnt.rays, cnt.nodeTests, cnt.triTests, cnt.attrFetches, cnt.gateTests, cnt.nodeVisits};
+        uint32_t vals[kCntCount] = {cnt.rays, cnt.nodeTests, cnt.triTests, cnt.attrFetches, cnt.gateTests, cnt.nodeVisits, cnt.tableFlops};
 #pragma unroll
         for (int c = 0; c < kCntCount; c++) {
             if (!STATS && c != kCntRays) continue;

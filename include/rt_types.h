@@ -204,6 +204,7 @@ typedef struct rt_frame_stats {
     uint64_t gate_tests;      /* whole-model bounding-box gate tests (stats launches only) */
     uint64_t split_waves;     /* extra waves the most recent block selection chose for the frame after it (0 = nothing split) */
     uint64_t node_visits;     /* octree nodes fetched, one 128-byte record each (stats launches only) */
+    uint64_t table_flops;     /* flops of the sphere / plane / box tests made on the linear tables: 30 / 14 / 26 each (stats launches only) */
 } rt_frame_stats;
 
 /* Sizes of the flattened device scene, for roofline accounting and tests. */
