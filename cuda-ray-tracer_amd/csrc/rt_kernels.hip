@@ -1143,6 +1143,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
     SceneK& S = A.scene;
     uint32_t blockIndex = blockIdx.x, gridBlocks = gridDim.x, frameIndex = 0;
     CamK cam = &P.camPos[0];
+    fetchPriority(true);      // until the wave knows its tile (order list, split list: dependent loads) - a new wave gets to its first rays quickly
     if (PATH) {
         // Workgroups are dispatched in index order, and the tile sequence of a frame starts with its most expensive tiles.
         // Frame after frame, the heavy tiles of the last frame would start when the launch is nearly over, and the launch
@@ -1240,6 +1241,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
     const uint32_t lx = bx + (lane & 7u), ly = by + (splitWave ? sub : (lane >> 3));
     const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
 
+    fetchPriority(false);
     Counters cnt; cnt.tableFlops = 0; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; cnt.nodeVisits = 0;
     const bool inFrame = pixelLane && x < P.width && y < P.height;
     {      // all 64 lanes, also those without a pixel: the mesh trace is a wave-wide operation
