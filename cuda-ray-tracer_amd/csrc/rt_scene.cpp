@@ -1,7 +1,7 @@
 // Scene flattening and octree construction (host).
 //
 // Replaces the reference's pointer-linked managed-memory octree (Octree.cpp:11-43, OctreeNode.cpp:3-14), which is
-// never built nor traversed there, by a spatial octree that is emitted directly as the flat 256-byte node array
+// never built nor traversed there, by a spatial octree that is emitted directly as the flat 128-byte node array
 // the kernels read.  The octree is only an accelerator: a mesh hit is defined by the reference's whole-model box
 // gate plus its linear triangle loop (Model.cpp:275-317), and the traversal kernel reproduces exactly that result.
 #include "rt_scene.h"

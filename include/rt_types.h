@@ -211,7 +211,7 @@ typedef struct rt_frame_stats {
 typedef struct rt_scene_info {
     int32_t sphereCount, planeCount, AABBCount, modelCount;
     int64_t triangleCount;     /* triangles the render path can hit (last one per model excluded) */
-    int64_t nodeCount;         /* 256-byte octree nodes */
+    int64_t nodeCount;         /* 128-byte octree nodes */
     int64_t leafCount;
     int32_t maxDepth;          /* deepest level reached */
     int64_t deviceBytes;       /* bytes resident in HBM for the scene */
