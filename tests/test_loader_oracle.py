@@ -5,7 +5,10 @@ a statement-by-statement restatement of the reference's loader (oracle/obj_loade
 Compared bit for bit: LoadedVertices (position, normal, texture coordinate), LoadedIndices, and per mesh its name, its
 vertices, its (always empty) index list and its material; LoadedMaterials.  The loader fixes triangle order - and with it
 which triangle wins an exact tie and which one is the never-tested last triangle of a model - so this is part of the
-render path's parity.  Parity unpinned against the reference itself (it holds no loader fixtures and cannot be built here).
+render path's parity.
+
+Pinned: where oracle/_ref exists (the reference's own OBJ_Loader.cpp compiled in this image, oracle/build_ref.sh), every
+case is also loaded by the reference's objl::Loader itself and the host loader's output is compared with that, bit for bit.
 """
 import ctypes as C
 import os
@@ -15,6 +18,7 @@ import numpy as np
 import pytest
 
 import host_lib
+import ref_lib
 from conftest import ROOT, load_package
 
 load_package()
@@ -64,10 +68,41 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
+def _assert_same_as_the_reference(path, host):
+    """The host loader's output against the reference's own objl::Loader (oracle/_ref) on the same file."""
+    path = str(path)
+    data = open(path, "rb").read()
+    if b"\r\n" in data:
+        # The reference opens its files in text mode (OBJ_Loader.cpp:191, 751), which on its own platform (Windows) turns
+        # CR LF into LF before getline sees the line; the build in oracle/_ref runs on Linux, where text mode translates
+        # nothing.  It is therefore given the text as its own platform would hand it over.
+        lf_dir = os.path.join(os.path.dirname(path), "as_text_mode_reads_it")
+        os.makedirs(lf_dir, exist_ok=True)
+        for name in os.listdir(os.path.dirname(path)):
+            src = os.path.join(os.path.dirname(path), name)
+            if os.path.isfile(src):
+                with open(os.path.join(lf_dir, name), "wb") as fh:
+                    fh.write(open(src, "rb").read().replace(b"\r\n", b"\n"))
+        path = os.path.join(lf_dir, os.path.basename(path))
+    r_ok, r_verts, r_idx, r_meshes, r_materials = ref_lib.ref().load_obj(path)
+    ok, verts, idx, meshes, materials = host
+    assert ok == r_ok
+    assert verts.shape == r_verts.shape and np.array_equal(_bits(verts), _bits(r_verts)), "LoadedVertices differ from the reference's"
+    assert np.array_equal(idx, r_idx), "LoadedIndices differ from the reference's"
+    assert len(meshes) == len(r_meshes) and len(materials) == len(r_materials)
+    for (name, nv, ni, mv, mname, mat), (r_name, r_nv, r_ni, r_mv, r_mname, r_mat) in zip(meshes, r_meshes):
+        assert (name, nv, ni, mname) == (r_name, r_nv, r_ni, r_mname)
+        assert np.array_equal(_bits(mv), _bits(r_mv)) and np.array_equal(_bits(mat), _bits(r_mat))
+    for (name, mapkd, mat), (r_name, r_mapkd, r_mat) in zip(materials, r_materials):
+        assert (name, mapkd) == (r_name, r_mapkd) and np.array_equal(_bits(mat), _bits(r_mat))
+
+
 def _compare(path):
     o = ref.Loader()
     o_ok = o.load_file(str(path))
-    ok, verts, idx, meshes, materials = _host_load(path)
+    ok, verts, idx, meshes, materials = host = _host_load(path)
+    if ref_lib.available():
+        _assert_same_as_the_reference(path, host)
     assert ok == o_ok
     o_verts = np.array([v.floats() for v in o.LoadedVertices], np.float32).reshape(-1, 8)
     assert verts.shape == o_verts.shape and np.array_equal(_bits(verts), _bits(o_verts)), "LoadedVertices differ"
@@ -120,7 +155,14 @@ def test_hand_written_obj_text(tmp_path, name):
         assert [m.MeshMaterial.name for m in o.LoadedMeshes] == ["Gold", "Wood", "none", "", ""]
 
 
-@pytest.mark.parametrize("model", ["cube", "Chalice", "Table", "Pizza"])
+def test_the_reference_loader_is_reachable_here():
+    """In this container the reference checkout is present, so the comparisons above must include the reference's own
+    loader; on a machine without the checkout and without a prebuilt oracle/_ref they fall back to the restatement only."""
+    if os.path.exists(os.path.join(ref_lib.REFERENCE_CHECKOUT, "OBJ_Loader.cpp")):
+        assert ref_lib.available()
+
+
+@pytest.mark.parametrize("model", ["cube", "Chalice", "Table", "Pizza", "Book2_Open", "Chest_gold", "Crown", "Vase", "Crystal3", "Chicken", "WoodLog"])
 def test_generated_models_load_identically(tmp_path, model):
     """The synthetic stand-ins for the reference's (absent) OBJ files, with the reference's own .mtl beside them."""
     meshes = host_lib.write_models(str(tmp_path), [model], 0.2)
