@@ -5,8 +5,10 @@ cuda-ray-tracer_amd/host/OBJ_Loader.cpp, a different (single-pass) parser whose 
 produces, because the loader fixes vertex and triangle order and therefore which triangle wins an exact tie and which
 triangle of a model is the never-tested last one.
 
-Parity unpinned: the reference holds no test, fixture or golden output for its loader and cannot be built here, so this file
-is pinned only against the reference's source text.  It follows that text statement by statement (file:line cited per
+Pinned: the reference holds no test, fixture or golden output for its loader, but its OBJ_Loader.cpp compiles in this image
+(oracle/build_ref.sh -> oracle/_ref/libref.so), and tests/test_loader_oracle.py loads every case with the reference's own
+objl::Loader as well: host loader, this restatement and the reference agree bit for bit.  The file follows the reference's
+text statement by statement (file:line cited per
 function, paths relative to the reference checkout), including the behaviour of its string helpers:
 
   algorithm::split       OBJ_Loader.h:193-229     algorithm::tail / firstToken   OBJ_Loader.h:232-266

@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Regenerates the golden frames under tests/golden/ with the CPU oracle.
 
-The reference ships no golden images and cannot be built in this image, so these vectors are outputs of the
-oracle (oracle/oracle.c), not of the reference itself: they pin the oracle against regressions and let the GPU
-path be checked without running the oracle.  Run from the repository root:  python tests/golden/make_golden.py
+The reference ships no golden images, and the file that holds its frame loop and shading (kernels.cu) does not compile
+outside MSVC + nvcc, so these whole-frame vectors are outputs of the oracle (oracle/oracle.c), not of the reference itself:
+they pin the oracle against regressions and let the GPU path be checked without running the oracle.  The vectors that DO
+come from the reference's own compiled routines are made by make_ref_golden.py (refgen_*.npz).  Run from the repository root:  python tests/golden/make_golden.py
 """
 import os
 import sys

@@ -1,6 +1,7 @@
 """Known-answer tests for the CPU oracle: values worked out by hand from the reference's formulas, plus the
-reference quirks that change pixels.  (The reference ships no golden vectors for this path: the oracle is
-"parity unpinned" against reference outputs; these tests pin it against the reference's source text.)"""
+reference quirks that change pixels.  (The reference ships no golden vectors for this path.  tests/test_ref_pins.py
+checks the routines that compile with g++ against the reference's own compiled code; the tests here pin the rest - boxes,
+shading, the trace loops - against the reference's source text.)"""
 import ctypes as C
 import math
 
