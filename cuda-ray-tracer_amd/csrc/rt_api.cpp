@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -110,6 +111,8 @@ struct rt_ctx {
     hipEvent_t pathCamsFree[kPathStaging] = {nullptr, nullptr, nullptr, nullptr};
     unsigned pathCalls = 0;
     rt::StaticScratch* staticScratch = nullptr;   // this device's record of the never-allocated scratch (rt_render_device_static)
+    // The stream whose launches last used the context's dispatch feedback and scene tables (see orderAfterOtherStreams).
+    hipStream_t lastStream = nullptr; bool lastStreamValid = false;
     bool strictOctreeFlag = false;   // config.octree hides meshes, as the reference's unfinished branch does
     bool forceDeviceBuild = false;   // RT_DEVICE_BUILD=1: build every scene's octrees on the GPU
     // what rt_validate_scene_device needs besides the device arrays
@@ -139,6 +142,33 @@ int ownedTileCount(int tiles, int rank, int world) {
     return (tiles - rank + world - 1) / world;
 }
 
+// The dispatch feedback (tile costs, the tile order ranked from them, the block lists) and the patched scene tables are written
+// by the launches of one call and read by those of the next.  Launches on one stream are ordered.  A call that arrives on
+// another stream than the last user's must not start while that one's launches are queued or running: a render launch that
+// reads a tile order while a ranking kernel rewrites it, or a ranking kernel that reads costs while a render launch raises
+// them, sees a list that is no permutation, and tiles go unrendered.  The new stream cannot be made to wait for the old one
+// (the caller may have destroyed it), so the host waits for the device.  A stream switch is rare - a context normally lives
+// on one stream - and costs nothing otherwise.
+int orderAfterOtherStreams(hipStream_t* last, bool* valid, hipStream_t stream) {
+    if (*valid && *last != stream) RT_HIP(hipDeviceSynchronize());
+    *last = stream;
+    *valid = true;
+    return RT_OK;
+}
+
+bool cameraWithinNoBoxRange(const rt_ctx* ctx, const float* camPos) {
+    // Without a bounding-box gate Model::hit also accepts hits behind the ray origin at any distance (Model.cpp:318-356),
+    // and the padding of the octree boxes covers the traversal's rounding error only up to about 3000 units between a ray
+    // origin and a mesh.  Primary and reflection rays start within 999 units of the camera.
+    float d2 = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        const float c = camPos[a];
+        const float d = c < ctx->meshLo[a] ? ctx->meshLo[a] - c : (c > ctx->meshHi[a] ? c - ctx->meshHi[a] : 0.0f);
+        d2 += d * d;
+    }
+    return d2 <= 1500.0f * 1500.0f;      // false for NaN
+}
+
 int checkFrameArgs(rt_ctx* ctx, int width, int height) {
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
     if (width <= 0 || height <= 0 || width > 65536 || height > 65536) return fail(RT_ERR_INVALID, "frame size out of range");
@@ -146,18 +176,8 @@ int checkFrameArgs(rt_ctx* ctx, int width, int height) {
     if (!ctx->haveState) return fail(RT_ERR_NO_STATE, "rt_update_frame_state has not been called");
     if (ctx->frame.meshMode == rt::kMeshEightBoxes && !ctx->chunksSequential)
         return fail(RT_ERR_INVALID, "eightBoundingBoxes needs models whose chunk boxes list their triangles in file order");
-    if (ctx->frame.meshMode == rt::kMeshNoBox && ctx->haveMeshBounds) {
-        // Without a bounding-box gate Model::hit also accepts hits behind the ray origin at any distance (Model.cpp:318-356),
-        // and the padding of the octree boxes covers the traversal's rounding error only up to about 3000 units between a ray
-        // origin and a mesh.  Primary and reflection rays start within 999 units of the camera.
-        float d2 = 0.0f;
-        for (int a = 0; a < 3; a++) {
-            const float c = ctx->frame.camPos[a];
-            const float d = c < ctx->meshLo[a] ? ctx->meshLo[a] - c : (c > ctx->meshHi[a] ? c - ctx->meshHi[a] : 0.0f);
-            d2 += d * d;
-        }
-        if (!(d2 <= 1500.0f * 1500.0f)) return fail(RT_ERR_INVALID, "boundingBox = false: the camera must stay within 1500 units of the meshes");
-    }
+    if (ctx->frame.meshMode == rt::kMeshNoBox && ctx->haveMeshBounds && !cameraWithinNoBoxRange(ctx, ctx->frame.camPos))
+        return fail(RT_ERR_INVALID, "boundingBox = false: the camera must stay within 1500 units of the meshes");
     // every entry point launches on the context's own device, whatever device the calling thread had current
     RT_HIP(hipSetDevice(ctx->device));
     return RT_OK;
@@ -211,6 +231,7 @@ int launchOrdered(rt_ctx* ctx, const rt::FrameParams& frame, uint8_t* out, int32
                   bool instrumented, hipStream_t stream, unsigned long long* waveClocks = nullptr) {
     const DispatchPlan plan = planDispatch(ctx, frame);
     const rt::FrameParams& p = plan.p;
+    if (int rc = orderAfterOtherStreams(&ctx->lastStream, &ctx->lastStreamValid, stream)) return rc;
     if (ctx->sphere0Dirty || ctx->plane0Dirty) {
         RT_HIP(rt::launchPatchTables(ctx->sphere0Dirty ? const_cast<rt::F4*>(ctx->scene.sphGeom) : nullptr, ctx->sphere0Geom,
                                      ctx->plane0Dirty ? const_cast<rt::F4*>(ctx->scene.plnMat) : nullptr, ctx->plane0Mat0, stream));
@@ -653,6 +674,11 @@ int rt_render_device_static(rt_ctx* ctx, int width, int height, void* d_rgb, voi
                                      " x " + std::to_string(RT_TILE) + " pixels, the static scratch holds " + std::to_string(rt::kStaticTiles));
     hipStream_t stream = static_cast<hipStream_t>(hip_stream);
     rt::StaticScratch& sc = *ctx->staticScratch;
+    // the context's own tables, then the array every context of this GPU shares: one caller at a time, and a caller on another
+    // stream than the array's last user waits for the device first
+    if (int rc2 = orderAfterOtherStreams(&ctx->lastStream, &ctx->lastStreamValid, stream)) return rc2;
+    std::lock_guard<std::mutex> guard(sc.lock);
+    if (int rc2 = orderAfterOtherStreams(&sc.lastStream, &sc.lastStreamValid, stream)) return rc2;
     if (ctx->sphere0Dirty || ctx->plane0Dirty) {
         RT_HIP(rt::launchPatchTables(ctx->sphere0Dirty ? const_cast<rt::F4*>(ctx->scene.sphGeom) : nullptr, ctx->sphere0Geom,
                                      ctx->plane0Dirty ? const_cast<rt::F4*>(ctx->scene.plnMat) : nullptr, ctx->plane0Mat0, stream));
@@ -690,6 +716,11 @@ int renderPath(rt_ctx* ctx, int width, int height, int rank, int world, bool com
     if (p.ownedTiles <= 0) return RT_OK;
     if ((unsigned long long)rt::launchGridBlocks(p) * (unsigned long long)nFrames > 0x7fffffffull)
         return fail(RT_ERR_CAPACITY, "too many workgroups for one launch: render the path in shorter pieces");
+    if (ctx->frame.meshMode == rt::kMeshNoBox && ctx->haveMeshBounds)
+        for (int f = 0; f < nFrames; f++)
+            if (!cameraWithinNoBoxRange(ctx, &cams[f].position.x))
+                return fail(RT_ERR_INVALID, "boundingBox = false: camera " + std::to_string(f) + " of the path is more than 1500 units from the meshes");
+    if (int rc = orderAfterOtherStreams(&ctx->lastStream, &ctx->lastStreamValid, stream)) return rc;
     const int slot = (int)(ctx->pathCalls++ % rt_ctx::kPathStaging);
     float* const staging = ctx->hPathCams + (size_t)slot * 16 * RT_MAX_PATH_FRAMES;
     RT_HIP(hipEventSynchronize(ctx->pathCamsFree[slot]));      // the copy of four path calls ago has left this staging slot

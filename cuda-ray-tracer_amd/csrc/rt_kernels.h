@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
+
 #include "rt_device_types.h"
 
 #define RT_TILE_PX 32   // must equal RT_TILE of the public header
@@ -40,7 +42,9 @@ hipError_t launchPatchTables(F4* sphGeom0, F4 sphere0, F4* plnMat0, F4 plane0Mat
 // words = this device's copy of the array: tile costs [0, kStaticTiles) and [kStaticTiles, 2 kStaticTiles), tile order after
 // them.  costSlot / orderKey say which cost buffer the next frame accumulates into and which frame geometry the order is for.
 constexpr int kStaticTiles = 32768;
-struct StaticScratch { uint32_t* words; int costSlot; long long orderKey; };
+// lock: held for the whole of a call that uses the array (host bookkeeping and the launches' enqueueing); lastStream: the stream
+// those launches went to.
+struct StaticScratch { uint32_t* words; int costSlot; long long orderKey; std::mutex lock; hipStream_t lastStream; bool lastStreamValid; };
 // Looks the array's address up on first use per device (which must be the current device) and returns that device's record.
 hipError_t staticScratch(int device, StaticScratch** out);
 

@@ -17,6 +17,7 @@ struct rt_comm {
     uint8_t* dTiles = nullptr; size_t tilesCap = 0;
     uint8_t* dGathered = nullptr; size_t gatheredCap = 0;     // rank 0 only
     uint8_t* dFrame = nullptr; size_t frameCap = 0;           // rank 0 only
+    int* dStatus = nullptr;                                   // two ints: this rank's status of the frame, the maximum over ranks
 };
 
 namespace {
@@ -65,6 +66,10 @@ int rt_comm_create(const unsigned char id[RT_COMM_ID_BYTES], int rank, int world
     if (r != ncclSuccess) { delete c; return fail(RT_ERR_DEVICE, std::string("ncclCommInitRank: ") + ncclGetErrorString(r)); }
     hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { rt_comm_destroy(c); return fail(RT_ERR_DEVICE, std::string("hipStreamCreate: ") + hipGetErrorString(e)); }
+    void* st = nullptr;
+    e = hipMalloc(&st, 2 * sizeof(int));
+    if (e != hipSuccess) { rt_comm_destroy(c); return fail(RT_ERR_DEVICE, std::string("hipMalloc(status): ") + hipGetErrorString(e)); }
+    c->dStatus = static_cast<int*>(st);
     *out = c;
     return RT_OK;
 }
@@ -76,6 +81,7 @@ void rt_comm_destroy(rt_comm* c) {
     if (c->dTiles) (void)hipFree(c->dTiles);
     if (c->dGathered) (void)hipFree(c->dGathered);
     if (c->dFrame) (void)hipFree(c->dFrame);
+    if (c->dStatus) (void)hipFree(c->dStatus);
     if (c->comm) (void)ncclCommDestroy(c->comm);
     delete c;
 }
@@ -94,13 +100,26 @@ int rt_render_frame_sharded(rt_ctx* ctx, rt_comm* c, int width, int height, uint
     const size_t per = rt_tile_buffer_bytes(width, height, c->world);
     if (per == 0) return fail(RT_ERR_INVALID, "bad frame size");
     RT_TRY_HIP(hipSetDevice(c->device));
-    int rc = ensure(&c->dTiles, &c->tilesCap, per);
-    if (rc) return rc;
+    // What can fail on this rank alone (an allocation, the render call's own checks) must not keep it out of the collectives:
+    // a rank that returned here would leave the others blocked in the gather for ever.  So every rank first takes part in a
+    // one-word all-reduce of its status, and the frame's gather only happens if every rank is ready for it.
+    int local = RT_OK;
+    std::string localError;
+    auto attempt = [&](int rc, const char* message) { if (local == RT_OK && rc != RT_OK) { local = rc; localError = message; } };
+    attempt(ensure(&c->dTiles, &c->tilesCap, per), g_error.c_str());
     if (c->rank == 0) {
-        if ((rc = ensure(&c->dGathered, &c->gatheredCap, per * (size_t)c->world))) return rc;
-        if ((rc = ensure(&c->dFrame, &c->frameCap, (size_t)width * (size_t)height * 3))) return rc;
+        attempt(ensure(&c->dGathered, &c->gatheredCap, per * (size_t)c->world), g_error.c_str());
+        attempt(ensure(&c->dFrame, &c->frameCap, (size_t)width * (size_t)height * 3), g_error.c_str());
     }
-    if (rt_render_tiles_device(ctx, width, height, c->rank, c->world, c->dTiles, per, c->stream) != RT_OK) return fail(RT_ERR_DEVICE, rt_last_error());
+    if (local == RT_OK && rt_render_tiles_device(ctx, width, height, c->rank, c->world, c->dTiles, per, c->stream) != RT_OK) attempt(RT_ERR_DEVICE, rt_last_error());
+    int anyFailed = 0;
+    RT_TRY_HIP(hipMemsetAsync(c->dStatus, local == RT_OK ? 0 : 1, sizeof(int), c->stream));
+    RT_TRY_NCCL(ncclAllReduce(c->dStatus, c->dStatus + 1, 1, ncclInt, ncclMax, c->comm, c->stream));
+    RT_TRY_HIP(hipMemcpyAsync(&anyFailed, c->dStatus + 1, sizeof(int), hipMemcpyDeviceToHost, c->stream));
+    RT_TRY_HIP(hipStreamSynchronize(c->stream));
+    if (local != RT_OK) return fail(local, localError);
+    if (anyFailed) return fail(RT_ERR_DEVICE, "another rank could not render its share of the frame");
+    int rc = RT_OK;
     if ((rc = rt_gather_tiles(c, c->dTiles, per, c->dGathered, c->stream))) return rc;
     if (c->rank == 0) {
         if (rt_untile_device(ctx, width, height, c->world, c->dGathered, c->dFrame, c->stream) != RT_OK) return fail(RT_ERR_DEVICE, rt_last_error());

@@ -15,15 +15,18 @@ void mix(unsigned long long& h, const void* data, size_t bytes) {      // FNV-1a
     for (size_t i = 0; i < bytes; i++) { h ^= p[i]; h *= 1099511628211ull; }
 }
 
-// Everything rt_upload_scene reads, except what travels with every frame anyway (camera, light, spheres[0] geometry,
-// planes[0] ambient colour).  Models are identified by their arrays (address and size) and their placement: the reference
-// never edits a model's vertices after construction.
+// Everything rt_upload_scene reads, except what travels with every frame anyway (camera, light position, spheres[0] geometry,
+// planes[0] ambient colour).  The light's colour and the octree build parameters only reach the GPU with an upload, so they are
+// part of it.  Models are identified by their arrays (address and size), their placement and a sample of their vertices: the
+// reference never edits a model's vertices after construction, but a model freed and rebuilt may land on the same addresses.
 unsigned long long sceneFingerprint(rt_scene_desc desc, SceneDescStorage storage) {
     unsigned long long h = 1469598103934665603ull;
     if (!storage.spheres.empty()) { storage.spheres[0].position = rt_vec3{0, 0, 0}; storage.spheres[0].radius = 0; }
     if (!storage.planes.empty()) storage.planes[0].mat.ambientColour = rt_vec3{0, 0, 0};
-    const int counts[4] = {desc.sphereCount, desc.planeCount, desc.AABBCount, desc.modelCount};
+    const int counts[7] = {desc.sphereCount, desc.planeCount, desc.AABBCount, desc.modelCount, desc.octreeMaxDepth, desc.octreeLeafTriangles,
+                           desc.buildOnDevice};
     mix(h, counts, sizeof counts);
+    for (const rt_light& l : storage.lights) mix(h, &l.colour, 12);
     // field by field where a struct has padding
     for (const rt_sphere& s : storage.spheres) { mix(h, &s.position, 12); mix(h, &s.radius, 4); mix(h, &s.mat, sizeof s.mat); mix(h, &s.objectType, 8); }
     for (const rt_plane& p : storage.planes) { mix(h, &p.position, 24); mix(h, &p.mat, sizeof p.mat); mix(h, &p.objectType, 8); }
@@ -32,6 +35,10 @@ unsigned long long sceneFingerprint(rt_scene_desc desc, SceneDescStorage storage
         mix(h, &m.position, 12); mix(h, &m.size, 4); mix(h, &m.mat, sizeof m.mat); mix(h, &m.objectType, 8);
         mix(h, &m.bbMin, 24); mix(h, &m.vertices, sizeof m.vertices); mix(h, &m.vertCount, 4);
         mix(h, &m.indices, sizeof m.indices); mix(h, &m.indicesCount, 4); mix(h, &m.octree, sizeof m.octree);
+        if (m.vertices && m.vertCount > 0)      // 64 vertices spread over the array
+            for (int k = 0; k < 64; k++) mix(h, &m.vertices[(long long)k * (m.vertCount - 1) / 63].position, 12);
+        if (m.indices && m.indicesCount > 0)
+            for (int k = 0; k < 64; k++) mix(h, &m.indices[(long long)k * (m.indicesCount - 1) / 63], 4);
     }
     return h ? h : 1ull;
 }

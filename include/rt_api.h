@@ -16,7 +16,12 @@
  *  - inputs are caller-owned and only read during the call; device memory is
  *    owned by the context.
  *  - a context is not re-entrant: one thread at a time per rt_ctx, exactly as
- *    the reference's single GLFW thread drives one RayTracer.
+ *    the reference's single GLFW thread drives one RayTracer.  A context keeps
+ *    dispatch feedback between frames (tile costs and the order ranked from
+ *    them), so its frames belong on ONE stream: a render call on another stream
+ *    than the context's previous one (the blocking entry points use a stream of
+ *    the context's own) first waits for the device to go idle.  For frames in
+ *    flight on several streams give each stream a context of its own.
  *  - host-pointer entry points block until the frame is complete (the
  *    reference's cudaDeviceSynchronize, RayTracer.cpp:416); *_device entry
  *    points enqueue on the given HIP stream and return.
@@ -111,9 +116,11 @@ int rt_render_device(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_
  * by every GPU the library runs on until the process ends.  Frames of more than 32768 tiles of RT_TILE x RT_TILE pixels
  * (7680 x 4320 has 32400) are rejected with RT_ERR_CAPACITY.  The call itself calls no hipMalloc / hipFree or allocating
  * routine; the scene must have been uploaded and the frame state set before.  Heavy blocks are not split in this variant.
- * Every call on a GPU shares that GPU's array, whichever context it comes through: calls that overlap on one GPU (two
- * streams, two threads) race on it - pixels stay correct (any tile order renders the same frame), the dispatch order may
- * not be the intended one.  The array keeps the last call's contents; a call for another frame geometry clears the costs.
+ * Every call on a GPU shares that GPU's array, whichever context it comes through.  Calls are serialised on the host by a
+ * lock, and a call on another stream than the array's previous user first waits for the device to go idle (the order list must
+ * not be read or ranked while another stream's launches still use it: a torn list would leave tiles unrendered), so frames
+ * issued through this entry point on several streams of one GPU do not overlap; use one stream per GPU for it.  The array
+ * keeps the last call's contents; a call for another frame geometry clears the costs.
  */
 int rt_render_device_static(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_stream);
 

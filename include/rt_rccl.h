@@ -41,6 +41,9 @@ int rt_gather_tiles(rt_comm* comm, const void* d_tiles, size_t bytes_per_rank, v
  * One sharded frame, blocking: this rank's tiles (rt_render_tiles_device), the gather, and on rank 0 the reassembly
  * (rt_untile_device) and the copy to rgb_out (host, 3 * width * height bytes; ignored on the other ranks).  Collective.
  * The multi-GPU form of rt_render_frame; device buffers are kept in the communicator and grown when a larger frame comes.
+ * A failure on one rank (an allocation, the render call's own checks) is agreed on with a one-word all-reduce before the
+ * gather, so every rank returns - the failing one with its own error, the others with RT_ERR_DEVICE - instead of waiting in
+ * the collective for a rank that has left.
  */
 int rt_render_frame_sharded(rt_ctx* ctx, rt_comm* comm, int width, int height, uint8_t* rgb_out);
 

@@ -455,9 +455,14 @@ static int trace_models(o_ctx* c, v3 o, v3 d, int rayType, o_hit* hit) {
 /* kernels.cu:44-46 / 295-297 — a point on the light's sphere from two hashed numbers */
 /* The reference's sin / cos / acos on floats are evaluated in double and rounded to float once: the correctly rounded
  * float result, which is what independent math libraries (this one, the GPU's, the reference's) can agree on. */
-static float cr_sinf(float x) { return (float)sin((double)x); }
-static float cr_cosf(float x) { return (float)cos((double)x); }
-static float cr_acosf(float x) { return (float)acos((double)x); }
+static int g_libm_float_trig = 0;
+static float cr_sinf(float x) { return g_libm_float_trig ? sinf(x) : (float)sin((double)x); }
+static float cr_cosf(float x) { return g_libm_float_trig ? cosf(x) : (float)cos((double)x); }
+static float cr_acosf(float x) { return g_libm_float_trig ? acosf(x) : (float)acos((double)x); }
+/* Test switch: evaluate the three functions with this machine's single-precision libm routines, i.e. the reference's own
+ * formulation (sin / cos / acos on float arguments, kernels.cu:44-46, 295-297) as one particular library computes it.  Used to
+ * bound how far the correctly rounded definition can move a frame away from such a build.  Not thread-safe; set between renders. */
+void oracle_set_libm_float_trig(int on) { g_libm_float_trig = on != 0; }
 
 static v3 light_sample_offset(unsigned int seed, const rt_config* g) {
     float radius = (float)g->softShadowRadius;
