@@ -20,6 +20,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 FP32_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak
+SHADER_CLOCK_HZ = 2.4e9    # MI355X peak engine clock
 
 
 WORKLOADS = {
@@ -115,9 +116,13 @@ def main():
     ap.add_argument("--tile-slots", type=int, default=3, help="several GPUs: tile-buffer slots per rank (gathers that can be in flight or being filled)")
     ap.add_argument("--frames-per-gather", type=int, default=0, help="several GPUs: consecutive frames whose tiles one gather moves (0 = 4 on two GPUs, 8 on four, 16 from eight on: a launch costs at least the run time of its heaviest block, however little it renders)")
     ap.add_argument("--device-build", type=int, default=0, help="1: build the octrees on the GPU (0.2 s for the 10 M triangles of config 5, frames 5 %% slower), 0: on the host (1.8 s)")
-    ap.add_argument("--path-frames", type=int, default=0,
+    ap.add_argument("--path-frames", type=int, default=120,
                     help="also render this many frames of the benchmark's moving-camera path (scenes.camera_path_pose): once frame by "
-                         "frame (frame state + one launch per frame) and once through the camera-path entry point (one launch per chunk)")
+                         "frame (frame state + one launch per frame) and once through the camera-path entry point (one launch per chunk); "
+                         "0 = skip")
+    ap.add_argument("--latency-steps", type=int, default=-1,
+                    help="several GPUs: frames of the latency leg - one frame per gather, one frame in flight, the host waits for every "
+                         "frame as the reference's loop does (launch, synchronise, present); -1 = as many as --steps (at most 100), 0 = skip")
     ap.add_argument("--path-chunk", type=int, default=0, help="frames per camera-path launch (0 = 30 on one GPU, the gather batch on several)")
     ap.add_argument("--launch-per-gather", type=int, default=-1,
                     help="several GPUs: 1 = the frames of one gather batch are rendered by ONE launch (the camera-path entry point, one "
@@ -412,6 +417,59 @@ def main():
         by_flight[str(other_flight)] = elapsed2 * 1e3 / steps2
         flight[0] = in_flight
 
+    # Latency mode on several GPUs: the reference keeps ONE frame in flight (RayTracer.cpp:405-417: launch, synchronise, then the
+    # host reads the frame).  One frame per gather, no batching, the host waits for the reassembled frame before it issues the next.
+    latency_ms = None
+    latency_steps = (min(args.steps, 100) if args.latency_steps < 0 else args.latency_steps) if tiled else 0
+    if latency_steps > 0:
+        fence()
+        ctx0, s0, _ = lanes[0]
+        lat_tiles = torch.empty(tile_bytes, dtype=torch.uint8, device=dev)
+        lat_gathered = torch.zeros(tile_bytes * share, dtype=torch.uint8, device=dev) if rank == 0 else None
+        lat_list = list(lat_gathered.chunk(share))[:world] if rank == 0 else None
+        lat_frame = torch.empty(pixels * 3, dtype=torch.uint8, device=dev) if rank == 0 else None
+        if backend != "nccl":
+            lat_host = torch.empty(tile_bytes, dtype=torch.uint8)
+            lat_host_all = torch.empty(tile_bytes * world, dtype=torch.uint8) if rank == 0 else None
+            lat_host_list = list(lat_host_all.chunk(world)) if rank == 0 else None
+
+        def latency_frame():
+            ctx0.render_tiles_device(w, h, rank, share, lat_tiles.data_ptr(), tile_bytes, s0.cuda_stream)
+            with torch.cuda.stream(s0):
+                if backend == "nccl":
+                    dist.gather(lat_tiles, lat_list, dst=0)
+                else:
+                    s0.synchronize()
+                    lat_host.copy_(lat_tiles)
+                    dist.gather(lat_host, lat_host_list, dst=0)
+                    if rank == 0:
+                        lat_gathered.narrow(0, 0, tile_bytes * world).copy_(lat_host_all)
+                if rank == 0:
+                    r.untile_device(w, h, share, lat_gathered.data_ptr(), lat_frame.data_ptr(), s0.cuda_stream)
+            torch.cuda.synchronize()
+
+        for _ in range(max(3, args.warmup)):
+            latency_frame()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(latency_steps):
+            latency_frame()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt = float(tmax.item())
+        latency_ms = dt * 1e3 / latency_steps
+        if rank == 0 and share == world:
+            latency_frame_equal = bool(torch.equal(lat_frame, last_frame[0].reshape(-1).to(lat_frame.device)))
+        else:
+            latency_frame_equal = None
+
     # The moving-camera frame loop of the reference (Window.cpp:339-421), on the benchmark's fixed camera path.
     path_result = None
     if args.path_frames > 0:
@@ -490,7 +548,7 @@ def main():
         if share == world:
             untimed, _ = r.render(w, h)
             check["equals_untimed_render"] = bool(np.array_equal(untimed, timed_frame))
-        traffic = None
+        traffic = valu_insts = lane_util = None
         # HBM bytes per launch from the PMC counters of an earlier profiling run of this workload (tools/profile_all.sh)
         tpath = os.path.join(ROOT, "profiles", f"traffic_config{args.config}.json")
         if not os.path.exists(tpath):
@@ -501,6 +559,8 @@ def main():
                     tj = json.load(f)
                 if tj.get("workload") == f"config{args.config}" and world == 1 and (w, h) == tuple(tj.get("size", ())) and (args.config != 5 or abs(args.detail - 7.0) < 1e-9):
                     traffic = tj.get("hbm_bytes_per_launch")
+                    valu_insts = tj.get("valu_instructions_per_launch")
+                    lane_util = tj.get("valu_lane_utilisation")
             except Exception:
                 traffic = None
         out = {
@@ -526,6 +586,13 @@ def main():
         }
         if path_result is not None:
             out["camera_path"] = path_result
+        if latency_ms is not None:
+            # beside the throughput figure above (frames gathered in batches, two batches in flight): what one frame takes from
+            # launch to reassembled frame with nothing else in flight, as the reference's own loop runs
+            out["ms_per_frame_latency"] = latency_ms
+            out["latency_mode"] = {"frames": latency_steps, "frames_per_gather": 1, "frames_in_flight": 1, "host_waits_every_frame": True,
+                                   "mrays_per_s": (rays / (share / world)) / (latency_ms * 1e-3) / 1e6,
+                                   "frame_equals_throughput_mode": latency_frame_equal}
         out["roofline"].update({
             "traffic": traffic, "scene_bytes": int(info.deviceBytes),
             "why_this_bound": (("scene resident in the 256 MB Infinity Cache: HBM is read about once per frame, the kernel is bound by FP32 "
@@ -538,6 +605,23 @@ def main():
             "hbm_frac_measured": (traffic / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
             "node_visits_per_ray": st.node_visits / rays, "node_tests_per_ray": st.node_tests / rays,
             "tri_tests_per_ray": st.tri_tests / rays, "attr_fetches_per_ray": st.attr_fetches / rays})
+        # What is left, said in the kernel's own currency.  The arithmetic contract (no contraction, correctly rounded division
+        # and square root) keeps the kernel off the packed-fma peak that `frac` is priced against; what it can be measured by is
+        # the share of the SIMDs' issue slots its vector instructions fill: instructions per launch (PMC pass of this workload,
+        # profiles/traffic_config*.json) x 4 cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz x the launch duration measured
+        # here).  1 - issue_frac is idle issue time; 1 - lane_utilisation is the share of lanes switched off in the instructions
+        # that do issue.  useful_flops_per_ray leaves out the traversal's speculative visits (subtrees entered for entries of a
+        # ray that were pending side by side and that the hit found meanwhile would have pruned): counted by a second pass of the
+        # instrumented kernel that is bounded by each ray's final hit distance from the start.
+        useful_f_ray = (26.0 * st.useful_node_tests + 51.0 * st.useful_tri_tests + 26.0 * st.gate_tests + float(st.table_flops)) / max(rays, 1) + 60.0
+        out["roofline"].update({
+            "useful_flops_per_ray": useful_f_ray,
+            "useful_frac": useful_f_ray * launch_rays / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+            "speculative_node_tests": 1.0 - st.useful_node_tests / max(int(st.node_tests), 1),
+            "speculative_tri_tests": 1.0 - st.useful_tri_tests / max(int(st.tri_tests), 1),
+            "issue_frac": (valu_insts * 4.0 / (1024.0 * SHADER_CLOCK_HZ * kernel_ms * 1e-3)) if valu_insts else None,
+            "lane_utilisation": lane_util,
+            "valu_instructions_per_launch": valu_insts})
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"], (sw, sh, sample_rgb, sample_rays) = cpu_baseline(scenes, built, cfg)
             # the CPU leg's frame doubles as a check of the GPU path on this very scene and camera

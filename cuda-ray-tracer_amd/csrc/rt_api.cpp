@@ -326,6 +326,7 @@ int renderToHost(rt_ctx* ctx, int width, int height, uint8_t* rgbOut, int32_t* i
     if (tOut) { rc = ensureCapacity(&ctx->dT, &ctx->tCap, pixels); if (rc) return rc; }
 
     rt::FrameParams p = frameFor(ctx, width, height, 0, 1, false);
+    if (instrumented) p.flags |= rt::kCfgCountUseful;
     const hipStream_t hs = ctx->hostStream;
     RT_HIP(hipMemsetAsync(ctx->dCounters, 0, sizeof(unsigned long long) * rt::kCounterWords, hs));
     RT_HIP(hipEventRecord(ctx->evStart, hs));
@@ -351,6 +352,9 @@ int renderToHost(rt_ctx* ctx, int width, int height, uint8_t* rgbOut, int32_t* i
         stats->gate_tests = counters[rt::kCntGateTests];
         stats->node_visits = counters[rt::kCntNodeVisits];
         stats->table_flops = counters[rt::kCntTableFlops];
+        stats->useful_node_tests = counters[rt::kCntUsefulNodeTests];
+        stats->useful_tri_tests = counters[rt::kCntUsefulTriTests];
+        stats->useful_node_visits = counters[rt::kCntUsefulNodeVisits];
         stats->split_waves = ctx->hSplitWaves ? *ctx->hSplitWaves : 0u;
     }
     return RT_OK;

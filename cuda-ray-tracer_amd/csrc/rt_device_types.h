@@ -123,7 +123,10 @@ enum : uint32_t {
     kCfgHardShadows = 1u << 0, kCfgSoftShadows = 1u << 1, kCfgAreaSpecular = 1u << 2, kCfgReflections = 1u << 3,
     kCfgReflectPlanes = 1u << 4, kCfgRenderBoxes = 1u << 5, kCfgRenderModels = 1u << 6, kCfgAmbient = 1u << 7,
     kCfgDiffuse = 1u << 8, kCfgSpecular = 1u << 9, kCfgAntiAlias = 1u << 10, kCfgCull = 1u << 11,
-    kCfgModelsVisible = 1u << 12   // false when the selected mesh mode renders nothing
+    kCfgModelsVisible = 1u << 12,  // false when the selected mesh mode renders nothing
+    // instrumented kernel only: every closest-hit mesh trace is repeated with the hit distance it found as the bound from the
+    // start, and what that second pass visits is counted as the trace's useful work (kCntUseful*)
+    kCfgCountUseful = 1u << 13
 };
 
 enum : uint32_t { kTravDirectStart = 1u << 0, kTravExpandSiblings = 1u << 1 };
@@ -164,7 +167,11 @@ struct SplitState {
 // Per-launch counters (one 64-bit word each), accumulated with one atomic per wave.  The buffer holds kCounterSlots sets of
 // them, one cache line apart; workgroup b adds to set b % kCounterSlots and the host adds the sets up.  (Thirty thousand
 // atomics on one address from eight XCDs take 0.26 ms, longer than the 1080p frame they count.)
-enum { kCntRays = 0, kCntNodeTests, kCntTriTests, kCntAttrFetches, kCntGateTests, kCntNodeVisits, kCntTableFlops, kCntCount };
+enum { kCntRays = 0, kCntNodeTests, kCntTriTests, kCntAttrFetches, kCntGateTests, kCntNodeVisits, kCntTableFlops,
+       // The pooled traversal works on several entries of a ray at once and so enters subtrees that the hit it finds later would
+       // have pruned.  These three count what a traversal that knew each ray's hit distance in advance visits (closest-hit traces:
+       // a second pass bounded by the result; any-hit traces: what they did visit).
+       kCntUsefulNodeTests, kCntUsefulTriTests, kCntUsefulNodeVisits, kCntCount };
 constexpr int kCounterSlots = 256;
 constexpr int kCounterStride = 16;          // 64-bit words from one set to the next
 constexpr int kCounterWords = kCounterSlots * kCounterStride;

@@ -251,7 +251,7 @@ struct Closest {
     float u, v;
 };
 
-struct Counters { uint32_t rays, nodeTests, triTests, attrFetches, gateTests, nodeVisits, tableFlops; };
+struct Counters { uint32_t rays, nodeTests, triTests, attrFetches, gateTests, nodeVisits, tableFlops, usefulNodeTests, usefulTriTests, usefulNodeVisits; };
 
 // The wave's working set in LDS for the mesh traversal (tracePool); everything is indexed by lane or by pool position.
 struct WaveLds {
@@ -424,12 +424,13 @@ RT_DEV float orderFloat(uint32_t m) { return ubits((m & 0x80000000u) ? (m & 0x7f
 // level) until there is room again.  A node turn adds at most one entry per lane to the pool of triangle work (the set
 // of leaves the ray hit in the node) and is only taken while that pool has room for 64 and holds fewer than RT_TRI_TURN_AT
 // entries; the triangle turns take the leaves off a set one by one, nearest first.
-template <bool ANYHIT, bool STATS>
+// TIMED: the call adds to the wave's section clocks and turn counts (instrumented kernel; off for its counting-only second pass).
+template <bool ANYHIT, bool STATS, bool TIMED = STATS>
 RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDebug, int meshMode, uint32_t poolCapacity, uint32_t trav, Closest& best, WaveLds lds, Counters& cnt) {
     const uint32_t forestRoot = S.forestRoot;
     if (forestRoot == kNoRoot) return false;
     const uint32_t nodeCapacity = poolCapacity & 0xffffu, triCapacity = poolCapacity >> 16;
-    SectionTimer<STATS> timerWhole;
+    SectionTimer<TIMED> timerWhole;
     const uint32_t lane = threadIdx.x & 63u;
     const int nMdl = S.nMdl;
     const bool positiveOnly = meshMode != kMeshNoBox;
@@ -460,7 +461,7 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
     unsigned long long gateBits = 0;
     const SlabRay own = makeSlabRay(o, d);
     if (hasRay && pregated) {
-        SectionTimer<STATS> timerG;
+        SectionTimer<TIMED> timerG;
         const SlabRay& sr = own;
         const bool fin = fmaxf(fmaxf(fabsf(sr.rd.x), fabsf(sr.rd.y)), fabsf(sr.rd.z)) < __builtin_inff();
         const F4* const tightMin = inGlobal(S.mdlTightMin), * const tightMax = inGlobal(S.mdlTightMax);
@@ -519,14 +520,14 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
         // a node turn adds at most one triangle entry per lane
         const bool nodeTurn = nodeCount != 0 && triCount < RT_TRI_TURN_AT && triCount + 65u <= triCapacity;
         if (nodeTurn) {
-            SectionTimer<STATS> timerA;
+            SectionTimer<TIMED> timerA;
             fetchPriority(true);
             const uint32_t room = nodeCapacity - nodeCount;
             // a lane's turn adds at most one entry net; 24 entries stay in reserve for a depth-first descent by single lanes
             const uint32_t width = room >= 88u ? 64u : (room > 25u ? room - 24u : 1u);
             const uint32_t take = nodeCount < width ? nodeCount : width;
             const bool mine = lane < take;
-            if (STATS && lane == 0) { lds.prof[14] += take; lds.prof[15] += 1ull + (64ull << 32); }
+            if (TIMED && lane == 0) { lds.prof[14] += take; lds.prof[15] += 1ull + (64ull << 32); }
             unsigned long long e = 0;
             if (mine) e = lds.nodePool[nodeCount - 1u - lane];
             nodeCount -= take;
@@ -642,7 +643,7 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
             }
             timerA.stop(lds, 0);
         } else {
-            SectionTimer<STATS> timerB;
+            SectionTimer<TIMED> timerB;
             fetchPriority(true);
             // A lane takes one entry and puts back at most two (the rest of a leaf set, the rest of a run of triangles): a full
             // turn needs 64 free entries; with fewer, one entry stays free, and in a full pool the newest entry is a run, which
@@ -651,7 +652,7 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
             const uint32_t width = room >= 64u ? 64u : (room >= 2u ? room - 1u : 1u);
             const uint32_t take = triCount < width ? triCount : width;
             const bool mine = lane < take;
-            if (STATS && lane == 0) { lds.prof[14] += take; lds.prof[15] += 1ull + (64ull << 32); }
+            if (TIMED && lane == 0) { lds.prof[14] += take; lds.prof[15] += 1ull + (64ull << 32); }
             unsigned long long e = 0;
             if (mine) e = lds.triPool[triCount - 1u - lane];
             triCount -= take;
@@ -972,7 +973,22 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
             SectionTimer<STATS> tm; traceAnalytic<STATS>(S, ro, rdir, level != 0, planesRun, level != 0, boxesRun, h, cnt.tableFlops); tm.stop(lds, 4);
         }
         // models are traced as primary rays at levels 0 and 2 (kernels.cu:229, 157), as reflection rays at 1 and 3
-        if (modelsVisible) tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, nodeCapacity, (uint32_t)P.traversal, h, lds, cnt);
+        if (modelsVisible) {
+            const uint32_t nodeTestsBefore = cnt.nodeTests, triTestsBefore = cnt.triTests, nodeVisitsBefore = cnt.nodeVisits;
+            tracePool<false, STATS>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, nodeCapacity, (uint32_t)P.traversal, h, lds, cnt);
+            if (STATS) {
+                if (flags & kCfgCountUseful) {
+                    // the same rays once more, bounded from the start by the distance just found: nothing nearer exists, so the
+                    // pass finds nothing and only counts what lies in front of the hit
+                    Counters again = {};
+                    Closest bound; bound.t = h.t; bound.kind = KIND_NONE; bound.idx = -1; bound.tri = -1; bound.u = 0; bound.v = 0;
+                    tracePool<false, true, false>(S, active, ro, rdir, cull, (level & 1) != 0, P.meshMode, nodeCapacity, (uint32_t)P.traversal, bound, lds, again);
+                    cnt.usefulNodeTests += again.nodeTests; cnt.usefulTriTests += again.triTests; cnt.usefulNodeVisits += again.nodeVisits;
+                } else {
+                    cnt.usefulNodeTests += cnt.nodeTests - nodeTestsBefore; cnt.usefulTriTests += cnt.triTests - triTestsBefore; cnt.usefulNodeVisits += cnt.nodeVisits - nodeVisitsBefore;
+                }
+            }
+        }
         if (IDS && level == 0 && active) primaryOut = h;
         V3 colour = background;
         bool next = false, lit = false, wantNext = false, add = false, shadowed = false;
@@ -1037,7 +1053,9 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
                 if (flags & kCfgModelsVisible) {   // the shadow traces ignore renderModels (kernels.cu:304)
                     const bool needModel = lit && !(hard && (bySphere || byBox));
                     Closest dummy; dummy.t = FAR_T; dummy.kind = KIND_NONE; dummy.idx = -1; dummy.tri = -1; dummy.u = 0; dummy.v = 0;
+                    const uint32_t nodeTestsBefore = cnt.nodeTests, triTestsBefore = cnt.triTests, nodeVisitsBefore = cnt.nodeVisits;
                     byModel = tracePool<true, STATS>(S, needModel, biased, sd, cull, true, P.meshMode, nodeCapacity, (uint32_t)P.traversal, dummy, lds, cnt);
+                    if (STATS) { cnt.usefulNodeTests += cnt.nodeTests - nodeTestsBefore; cnt.usefulTriTests += cnt.triTests - triTestsBefore; cnt.usefulNodeVisits += cnt.nodeVisits - nodeVisitsBefore; }
                 }
                 if (lit) {
                     if (hard) shadowed = bySphere || byBox || byModel;
@@ -1243,6 +1261,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
 
     fetchPriority(false);
     Counters cnt; cnt.tableFlops = 0; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; cnt.nodeVisits = 0;
+    cnt.usefulNodeTests = 0; cnt.usefulTriTests = 0; cnt.usefulNodeVisits = 0;
     const bool inFrame = pixelLane && x < P.width && y < P.height;
     {      // all 64 lanes, also those without a pixel: the mesh trace is a wave-wide operation
         const V3 camPos = mk(cam);
@@ -1310,7 +1329,8 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
     // one atomic per wave and counter
     unsigned long long* counters = inGlobal(A.counters);
     if (counters) {
-        uint32_t vals[kCntCount] = {cnt.rays, cnt.nodeTests, cnt.triTests, cnt.attrFetches, cnt.gateTests, cnt.nodeVisits, cnt.tableFlops};
+        uint32_t vals[kCntCount] = {cnt.rays, cnt.nodeTests, cnt.triTests, cnt.attrFetches, cnt.gateTests, cnt.nodeVisits, cnt.tableFlops,
+                                    cnt.usefulNodeTests, cnt.usefulTriTests, cnt.usefulNodeVisits};
 #pragma unroll
         for (int c = 0; c < kCntCount; c++) {
             if (!STATS && c != kCntRays) continue;

@@ -101,7 +101,8 @@ class Dynamic(C.Structure):
 class FrameStats(C.Structure):
     _fields_ = [("gpu_ms", C.c_double), ("rays", C.c_uint64), ("node_tests", C.c_uint64),
                 ("tri_tests", C.c_uint64), ("attr_fetches", C.c_uint64), ("gate_tests", C.c_uint64), ("split_waves", C.c_uint64),
-                ("node_visits", C.c_uint64), ("table_flops", C.c_uint64)]
+                ("node_visits", C.c_uint64), ("table_flops", C.c_uint64), ("useful_node_tests", C.c_uint64),
+                ("useful_tri_tests", C.c_uint64), ("useful_node_visits", C.c_uint64)]
 
 
 class SceneInfo(C.Structure):

@@ -205,6 +205,13 @@ typedef struct rt_frame_stats {
     uint64_t split_waves;     /* extra waves the most recent block selection chose for the frame after it (0 = nothing split) */
     uint64_t node_visits;     /* octree nodes fetched, one 128-byte record each (stats launches only) */
     uint64_t table_flops;     /* flops of the sphere / plane / box tests made on the linear tables: 30 / 14 / 26 each (stats launches only) */
+    /* The traversal works on several pending entries of a ray at once, so it also enters subtrees that the hit it finds later
+     * would have pruned.  These count what a traversal that knew every ray's hit distance in advance would do: for closest-hit
+     * traces a second, counting-only pass bounded by the result (rt_render_frame_ids and rt_count_rays run it); for any-hit
+     * traces what they did.  node_tests - useful_node_tests etc. is the speculative share. */
+    uint64_t useful_node_tests;
+    uint64_t useful_tri_tests;
+    uint64_t useful_node_visits;
 } rt_frame_stats;
 
 /* Sizes of the flattened device scene, for roofline accounting and tests. */
