@@ -739,7 +739,10 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
             found = bk == 0ull;
         } else if (bk != init) {
             // the winning triangle once more, for t, u and v
-            const uint32_t record = lds.bestRec[lane];
+            // (the lane number passes through an empty asm statement so that this address is formed here: formed once at the top of
+            // the kernel, it would occupy a register through every trace of the pixel)
+            uint32_t self = lane; asm volatile("" : "+v"(self));
+            const uint32_t record = lds.bestRec[self];
             const F4* tp = tris + (size_t)record * 3;
             const f4_t A = ld4(tp), B = ld4(tp + 1), C = ld4(tp + 2);
             V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
@@ -846,7 +849,21 @@ RT_DEV bool shadowBoxes(SceneK& S, V3 o, V3 d, uint32_t& flops) {
 // the frame parameters, computed on the host with the same three divisions and square root).
 // L = normalise(lightPos - point), which the caller also needs as the direction of the hard shadow ray (kernels.cu:22 and :269
 // evaluate the same expression).
-RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 L, V3 v, V3 normal, FrameK& P, int px, int py) {
+// Where a wave's pixels lie: the frame coordinates of its lane 0 (wave-uniform, kept in scalar registers for the whole kernel).
+// A lane's own pixel is worked out from them where it is needed - for the camera ray at the start, for the sample seeds of
+// soft shadows, for the stores at the end - instead of being kept in two vector registers from the first use to the last
+// (which, at 128 registers, were spilled: every wave wrote its scratch, and the lines went back to HBM after it).
+struct PixelBase { uint32_t x0, y0; bool rows; };      // rows: lane l is pixel (x0 + (l & 7), y0 + (l >> 3)); else (x0 + (l & 7), y0)
+RT_DEV int pixelX(PixelBase b) {
+    uint32_t x0 = b.x0; asm volatile("" : "+s"(x0));       // opaque: worked out afresh at every use
+    return (int)(x0 + (threadIdx.x & 7u));
+}
+RT_DEV int pixelY(PixelBase b) {
+    uint32_t y0 = b.y0; asm volatile("" : "+s"(y0));
+    return (int)(y0 + (b.rows ? ((threadIdx.x & 63u) >> 3) : 0u));
+}
+
+RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 L, V3 v, V3 normal, FrameK& P, PixelBase pixel) {
     V3 colour = mk(0, 0, 0);
     const uint32_t flags = P.flags;
     if (flags & kCfgAmbient) colour = (lightCol * mat.ka) * mat.ambient;
@@ -864,6 +881,7 @@ RT_DEV V3 lighting(const Mat& mat, V3 lightPos, V3 lightCol, V3 point, V3 L, V3 
         if (flags & kCfgAreaSpecular) {
             const int softNum = P.softNum;
             const float softRadius = P.softRadius;
+            const int px = pixelX(pixel), py = pixelY(pixel);
             for (int i = 0; i < softNum; i++) {
                 V3 ps = lightSampleOffset(sampleSeed(px, py, i), softRadius);
                 V3 Ls = normalise((lightPos + ps) - point);
@@ -940,7 +958,7 @@ RT_DEV int renormCount(int kind, bool planesRun, bool boxesRun, bool modelsRun) 
 // and a lane without a ray at that point - outside the frame, chain ended, nothing to shade - passes hasRay = false and
 // lends its lane to the others.  `live`: the lane has a camera sample at all.
 template <bool STATS, bool IDS>
-RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int px, int py, WaveLds lds, Counters& cnt, Closest& primaryOut) {
+RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, PixelBase pixel, WaveLds lds, Counters& cnt, Closest& primaryOut) {
     const V3 background = mk(P.background);
     V3 lvl0 = background, lvl1 = background, lvl2 = background, lvl3 = background;
     float str0 = 0, str1 = 0, str2 = 0;
@@ -1008,7 +1026,7 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
                 else nLight = normalise(s.normal);
                 const V3 lightPos = mk(S.lightPos);
                 toLight = normalise(lightPos - s.point);
-                colour = lighting(s.mat, lightPos, mk(S.lightCol), s.point, toLight, mk(cam + 13), nLight, P, px, py);
+                colour = lighting(s.mat, lightPos, mk(S.lightCol), s.point, toLight, mk(cam + 13), nLight, P, pixel);
                 lit = true;
                 point = s.point; normal = s.normal;
                 biased = s.point + s.normal * P.shadowBias;
@@ -1039,7 +1057,7 @@ RT_DEV V3 castSample(SceneK& S, FrameK& P, CamK cam, bool live, V3 o, V3 d, int 
                 bool bySphere = false, byBox = false;
                 if (lit) {
                     if (!hard) {
-                        V3 ps = lightSampleOffset(sampleSeed(px, py, q - hardRays), P.softRadius);
+                        V3 ps = lightSampleOffset(sampleSeed(pixelX(pixel), pixelY(pixel), q - hardRays), P.softRadius);
                         V3 lightPoint = mk(S.lightPos) + ps;
                         sd = normalise(lightPoint - point);
                     }
@@ -1250,14 +1268,18 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
         }
         return;
     }
+    // (the tile came from a vector load of the order list: the same value in every lane, said so here so that everything derived
+    // from it is scalar)
+    localTile = (uint32_t)__builtin_amdgcn_readfirstlane((int)localTile); inTile = (uint32_t)__builtin_amdgcn_readfirstlane((int)inTile);
+    sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
     const uint32_t tile = localTile * (uint32_t)P.world + (uint32_t)P.rank;
-    const uint32_t tileX = tile % (uint32_t)P.tilesX, tileY = tile / (uint32_t)P.tilesX;
+    const uint32_t tileX = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile % (uint32_t)P.tilesX)), tileY = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile / (uint32_t)P.tilesX));
     // the waves of a tile walk it in Z order (neighbours in time are neighbours on screen).  A regular wave renders the whole
     // 8x8 block, lane l = pixel (l & 7, l >> 3); a split wave renders row `sub` of the block with its first eight lanes.
-    const uint32_t bx = evenBits3(inTile) * 8u, by = evenBits3(inTile >> 1) * 8u;
+    const uint32_t bx = evenBits3(inTile) * 8u, by = evenBits3(inTile >> 1) * 8u + (splitWave ? sub : 0u);
     const bool pixelLane = !splitWave || lane < 8u;
-    const uint32_t lx = bx + (lane & 7u), ly = by + (splitWave ? sub : (lane >> 3));
-    const int x = (int)(tileX * RT_TILE_PX + lx), y = (int)(tileY * RT_TILE_PX + ly);
+    PixelBase pixel; pixel.x0 = tileX * RT_TILE_PX + bx; pixel.y0 = tileY * RT_TILE_PX + by; pixel.rows = !splitWave;
+    const int x = pixelX(pixel), y = pixelY(pixel);
 
     fetchPriority(false);
     Counters cnt; cnt.tableFlops = 0; cnt.rays = 0; cnt.nodeTests = 0; cnt.triTests = 0; cnt.attrFetches = 0; cnt.gateTests = 0; cnt.nodeVisits = 0;
@@ -1276,17 +1298,18 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
 #pragma unroll 1
         for (int sIdx = 0; sIdx < samples; sIdx++) {
             const float offX = antiAlias ? ((sIdx & 2) ? 0.75f : 0.25f) : 0.5f, offY = antiAlias ? ((sIdx & 1) ? 0.75f : 0.25f) : 0.5f;
-            V3 p = rasterToCameraSpace(P, cam, (float)x + offX, (float)y + offY);
+            V3 p = rasterToCameraSpace(P, cam, (float)pixelX(pixel) + offX, (float)pixelY(pixel) + offY);
             Closest ph;
-            V3 c = castSample<STATS, IDS>(S, P, cam, inFrame, camPos, normalise(p), x, y, lds, cnt, ph);
+            V3 c = castSample<STATS, IDS>(S, P, cam, inFrame, camPos, normalise(p), pixel, lds, cnt, ph);
             if (IDS && sIdx == 0) primary = ph;
             total = antiAlias ? total + c : c;
         }
         col = antiAlias ? total / 4.0f : total;
         if (inFrame) {
+            const int xo = pixelX(pixel), yo = pixelY(pixel);      // the lane's pixel, worked out again (see PixelBase)
             size_t pix;
-            if (P.compactOutput) pix = (size_t)localTile * (RT_TILE_PX * RT_TILE_PX) + (size_t)ly * RT_TILE_PX + lx;
-            else pix = (size_t)y * (size_t)P.width + (size_t)x;
+            if (P.compactOutput) pix = (size_t)localTile * (RT_TILE_PX * RT_TILE_PX) + (size_t)((uint32_t)yo % RT_TILE_PX) * RT_TILE_PX + ((uint32_t)xo % RT_TILE_PX);
+            else pix = (size_t)yo * (size_t)P.width + (size_t)xo;
             uint8_t* out = inGlobal(A.out);
             if (PATH) out += (size_t)frameIndex * A.pathFrameBytes;
             int32_t* ids = IDS ? inGlobal(A.ids) : nullptr;
@@ -1295,7 +1318,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
             out[pix * 3 + 1] = packChannel(col.y);
             out[pix * 3 + 2] = packChannel(col.z);
             if (ids) {
-                size_t fp = (size_t)y * (size_t)P.width + (size_t)x;
+                size_t fp = (size_t)yo * (size_t)P.width + (size_t)xo;
                 bool hit = primary.kind != KIND_NONE;
                 ids[fp * 2 + 0] = hit ? ((primary.kind << 24) | (primary.idx & 0xFFFFFF)) : -1;
                 // (a model hit holds its position in the scene-wide attribute array; the caller gets the triangle's index in its model)
@@ -1304,7 +1327,7 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
                 ids[fp * 2 + 1] = hit ? triId : -1;
                 if (tbuf) tbuf[fp] = primary.t;
             } else if (tbuf) {
-                tbuf[(size_t)y * (size_t)P.width + (size_t)x] = primary.t;
+                tbuf[(size_t)yo * (size_t)P.width + (size_t)xo] = primary.t;
             }
         }
     }
