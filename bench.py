@@ -20,7 +20,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E peak
 FP32_PEAK_TFLOPS = 157.3   # MI355X FP32 vector peak
-SHADER_CLOCK_HZ = 2.4e9    # MI355X peak engine clock
 
 
 WORKLOADS = {
@@ -548,7 +547,7 @@ def main():
         if share == world:
             untimed, _ = r.render(w, h)
             check["equals_untimed_render"] = bool(np.array_equal(untimed, timed_frame))
-        traffic = valu_insts = lane_util = None
+        traffic = valu_insts = lane_util = gpu_cycles = None
         # HBM bytes per launch from the PMC counters of an earlier profiling run of this workload (tools/profile_all.sh)
         tpath = os.path.join(ROOT, "profiles", f"traffic_config{args.config}.json")
         if not os.path.exists(tpath):
@@ -561,6 +560,7 @@ def main():
                     traffic = tj.get("hbm_bytes_per_launch")
                     valu_insts = tj.get("valu_instructions_per_launch")
                     lane_util = tj.get("valu_lane_utilisation")
+                    gpu_cycles = tj.get("gpu_cycles_per_launch")
             except Exception:
                 traffic = None
         out = {
@@ -607,11 +607,12 @@ def main():
             "tri_tests_per_ray": st.tri_tests / rays, "attr_fetches_per_ray": st.attr_fetches / rays})
         # What is left, said in the kernel's own currency.  The arithmetic contract (no contraction, correctly rounded division
         # and square root) keeps the kernel off the packed-fma peak that `frac` is priced against; what it can be measured by is
-        # the share of the SIMDs' issue slots its vector instructions fill: instructions per launch (PMC pass of this workload,
-        # profiles/traffic_config*.json) x 4 cycles per wave64 instruction / (1024 SIMDs x 2.4 GHz x the launch duration measured
-        # here).  1 - issue_frac is idle issue time; 1 - lane_utilisation is the share of lanes switched off in the instructions
-        # that do issue.  useful_flops_per_ray leaves out the traversal's speculative visits (subtrees entered for entries of a
-        # ray that were pending side by side and that the hit found meanwhile would have pruned): counted by a second pass of the
+        # the share of the SIMDs' issue slots its vector instructions fill: instructions per launch x 4 cycles per wave64
+        # instruction / (1024 SIMDs x shader cycles of the launch), both from the PMC pass of this workload
+        # (profiles/traffic_config*.json; the clock is the one the GPU really ran at: cycles / launch duration, about 2.5 GHz).
+        # 1 - issue_frac is idle issue time; 1 - lane_utilisation is the share of lanes switched off in the instructions that
+        # do issue.  useful_flops_per_ray leaves out the traversal's speculative visits (subtrees entered for entries of a ray
+        # that were pending side by side and that the hit found meanwhile would have pruned): counted by a second pass of the
         # instrumented kernel that is bounded by each ray's final hit distance from the start.
         useful_f_ray = (26.0 * st.useful_node_tests + 51.0 * st.useful_tri_tests + 26.0 * st.gate_tests + float(st.table_flops)) / max(rays, 1) + 60.0
         out["roofline"].update({
@@ -619,7 +620,8 @@ def main():
             "useful_frac": useful_f_ray * launch_rays / (kernel_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
             "speculative_node_tests": 1.0 - st.useful_node_tests / max(int(st.node_tests), 1),
             "speculative_tri_tests": 1.0 - st.useful_tri_tests / max(int(st.tri_tests), 1),
-            "issue_frac": (valu_insts * 4.0 / (1024.0 * SHADER_CLOCK_HZ * kernel_ms * 1e-3)) if valu_insts else None,
+            "issue_frac": (valu_insts * 4.0 / (1024.0 * gpu_cycles)) if valu_insts and gpu_cycles else None,
+            "shader_clock_ghz": (gpu_cycles / (kernel_ms * 1e-3) / 1e9) if gpu_cycles else None,
             "lane_utilisation": lane_util,
             "valu_instructions_per_launch": valu_insts})
         if world == 1 and not args.no_cpu_baseline:

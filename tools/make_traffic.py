@@ -15,5 +15,7 @@ out = {"workload": sys.argv[2] if len(sys.argv) > 2 else "config3", "size": [int
        # 4 cycles; 256 CUs x 4 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs
        "valu_issue_busy": summary["SQ_INSTS_VALU"] * 4.0 / max(1024.0 * summary["GRBM_GUI_ACTIVE"] / 8.0, 1.0),
        "valu_instructions_per_launch": summary["SQ_INSTS_VALU"],
+       # shader-clock cycles the launch lasted (GRBM_GUI_ACTIVE is summed over the 8 XCDs)
+       "gpu_cycles_per_launch": summary["GRBM_GUI_ACTIVE"] / 8.0,
        "source": "rocprofv3 --pmc, separate passes (tools/profile_pmc.sh), mean over the renderKernel<false> dispatches"}
 print(json.dumps(out, indent=1))
