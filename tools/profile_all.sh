@@ -1,13 +1,13 @@
 #!/bin/bash
 # Kernel-trace statistics, the PMC passes and the derived traffic summary of one benchmark configuration, all with block
 # splitting off (under the profiler the selection would decide differently from the unprofiled bench) and without the
-# bench's second leg (every launch of the run is then of one kind).  Run on the GPU box from the repo root:
+# bench's second leg and camera-path legs (every launch of the run is then of one kind).  Run on the GPU box from the repo root:
 #   bash tools/profile_all.sh <tag> <config> <width> <height> [more bench.py arguments]
 # Results land in gpurun_out/<tag>/; copy the summaries to keep into profiles/.
 set -u
 TAG=${1:-r02}; CONFIG=${2:-3}; W=${3:-1920}; H=${4:-1080}; shift 4 || true
 export RT_SPLIT=0
-export BENCH_ARGS="--config $CONFIG --no-second-leg $*"
+export BENCH_ARGS="--config $CONFIG --no-second-leg --path-frames 0 $*"
 OUT=gpurun_out/$TAG
 rm -rf "$OUT"; mkdir -p "$OUT/prof"
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
