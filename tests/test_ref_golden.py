@@ -58,7 +58,7 @@ def test_oracle_reproduces_the_reference_mesh_hits(oracle, name):
     # and the routine by itself: interpolated normal / Ka / Kd
     verts12, indices = ref_golden.model_arrays(built.desc.models[0])
     n = w * h
-    from test_ref_pins import _p as p
+    p = _p
     cam = fx["cam_pos"]
     raw = np.zeros((h, w, 3), np.float32); direction = np.zeros((h, w, 3), np.float32)
     oracle.lib.oracle_kat_camera_rays(C.byref(built.camera), w, h, 0, 0, w, h, C.c_double(0.5), C.c_double(0.5), p(raw), p(direction))
