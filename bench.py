@@ -114,6 +114,12 @@ def main():
                          "8x8 block and leaves most of the GPU idle)")
     ap.add_argument("--tile-slots", type=int, default=3, help="several GPUs: tile-buffer slots per rank (gathers that can be in flight or being filled)")
     ap.add_argument("--frames-per-gather", type=int, default=0, help="several GPUs: consecutive frames whose tiles one gather moves (0 = 4 on two GPUs, 8 on four, 16 from eight on: a launch costs at least the run time of its heaviest block, however little it renders)")
+    ap.add_argument("--tile-deal", type=str, default="auto",
+                    help="several GPUs: how tiles are dealt to the ranks, 'k0,k1' = rank 0 gets k0 and every other rank k1 of each period of consecutive tiles "
+                         "(1,1 = plain interleaving); auto = rank 0's share reduced by what gathering and reassembling a frame costs it (--reassembly-share)")
+    ap.add_argument("--reassembly-share", type=float, default=0.027,
+                    help="time rank 0 spends on the gather and the reassembly of a frame, as a fraction of the time one GPU needs to render the frame "
+                         "(measured on one GPU for the 1080p benchmark frame: 6 of 224 us)")
     ap.add_argument("--device-build", type=int, default=0, help="1: build the octrees on the GPU (0.2 s for the 10 M triangles of config 5, frames 5 %% slower), 0: on the host (1.8 s)")
     ap.add_argument("--path-frames", type=int, default=120,
                     help="also render this many frames of the benchmark's moving-camera path (scenes.camera_path_pose): once frame by "
@@ -195,6 +201,11 @@ def main():
     share = world
     if tiled and world == 1 and int(os.environ.get("RT_BENCH_EMULATE_WORLD", "0")) > 1:
         share = int(os.environ["RT_BENCH_EMULATE_WORLD"])
+    from cuda_ray_tracer_amd import sharding
+    deal = sharding.balanced_deal(share, args.reassembly_share) if args.tile_deal == "auto" else tuple(int(v) for v in args.tile_deal.split(","))
+    if share == 1:
+        deal = (1, 1)
+    r.set_tile_deal(*deal)
     in_flight = args.frames_in_flight if args.frames_in_flight > 0 else (2 if share > 1 else 1)
     # The headline leg runs with `in_flight` frames in flight; a second, shorter leg repeats the measurement with the other of
     # 1 and 2, so that results at every GPU count can be compared like for like (ms_per_step_by_frames_in_flight).
@@ -214,6 +225,7 @@ def main():
         extra = binding.Renderer(device_index)
         extra.upload(built.desc)
         extra.set_state(built.camera, cfg)
+        extra.set_tile_deal(*deal)
         lanes.append((extra, torch.cuda.Stream(device=dev), None if tiled else torch.empty(pixels * 3, dtype=torch.uint8, device=dev)))
     if tiled:
         # A slot holds the tile buffers of `batch` consecutive frames, which one gather moves (the host cost of a collective
@@ -222,7 +234,7 @@ def main():
         # bounds how many frames the pipeline holds.
         batch = max(1, args.frames_per_gather if args.frames_per_gather > 0 else ((16 if share >= 8 else 8 if share >= 4 else 4) if share > 1 else 1))
         slots = max(2, args.tile_slots)
-        tile_bytes = binding.tile_buffer_bytes(w, h, share)
+        tile_bytes = binding.tile_buffer_bytes(w, h, share, deal)
         slot_bytes = tile_bytes * batch
         tiles = [torch.empty(slot_bytes, dtype=torch.uint8, device=dev) for _ in range(slots)]
         gathered = [torch.zeros(slot_bytes * share, dtype=torch.uint8, device=dev) for _ in range(slots)] if rank == 0 else [None] * slots
@@ -571,7 +583,7 @@ def main():
             "config": {"workload": WORKLOADS[args.config].format(w=w, h=h, depth=cfg.maxDepth, detail=args.detail),
                        "triangles": int(info.triangleCount), "octree_nodes": int(info.nodeCount), "rays_per_frame": rays,
                        "rays_per_pixel": rays / pixels, "tile": binding.RT_TILE, "octrees_built_on": "gpu" if device_build else "host",
-                       "frames_in_flight": in_flight, "frames_per_gather": batch if tiled else None,
+                       "frames_in_flight": in_flight, "frames_per_gather": batch if tiled else None, "tile_deal": list(deal) if tiled else None,
                        "frames_per_launch": (batch if batch_launch[0] else 1) if tiled else 1,
                        "launches_overlap": in_flight > 1,
                        "parallelism": ("1 GPU" if not tiled else f"1 GPU through the tile / gather / reassembly path (rehearsal, share of {share} ranks)") if world == 1 else f"image tiles over {world} GPUs, scene replicated, RCCL gather to rank 0"},

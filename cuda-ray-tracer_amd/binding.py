@@ -46,6 +46,10 @@ def lib():
     L.rt_render_path_tiles_device.argtypes = [vp, i32, i32, i32, i32, i32, C.POINTER(T.Camera), vp, sz, vp]
     L.rt_tile_buffer_bytes.argtypes = [i32, i32, i32]
     L.rt_tile_buffer_bytes.restype = sz
+    L.rt_tile_buffer_bytes_dealt.argtypes = [i32, i32, i32, i32, i32]
+    L.rt_tile_buffer_bytes_dealt.restype = sz
+    L.rt_set_tile_deal.argtypes = [vp, i32, i32]
+    L.rt_get_tile_deal.argtypes = [vp, C.POINTER(i32), C.POINTER(i32)]
     L.rt_render_tiles_device.argtypes = [vp, i32, i32, i32, i32, vp, sz, vp]
     L.rt_untile_device.argtypes = [vp, i32, i32, i32, vp, vp, vp]
     L.rt_untile_strided_device.argtypes = [vp, i32, i32, i32, vp, sz, vp, vp]
@@ -145,6 +149,10 @@ class Renderer:
         _check(lib().rt_render_path_tiles_device(self._ctx, width, height, rank, world, len(cameras), arr, C.c_void_p(d_tiles_ptr),
                                                  frame_stride_bytes, C.c_void_p(stream or 0)))
 
+    def set_tile_deal(self, rank0_slots, other_slots):
+        """How the tile entry points of this context deal a frame's tiles to the ranks (rt_set_tile_deal; default 1 / 1)."""
+        _check(lib().rt_set_tile_deal(self._ctx, rank0_slots, other_slots))
+
     def render_tiles_device(self, width, height, rank, world, d_tiles_ptr, capacity, stream=None):
         _check(lib().rt_render_tiles_device(self._ctx, width, height, rank, world, C.c_void_p(d_tiles_ptr), capacity,
                                             C.c_void_p(stream or 0)))
@@ -211,5 +219,5 @@ class FlatOctree:
             pass
 
 
-def tile_buffer_bytes(width, height, world):
-    return int(lib().rt_tile_buffer_bytes(width, height, world))
+def tile_buffer_bytes(width, height, world, deal=(1, 1)):
+    return int(lib().rt_tile_buffer_bytes_dealt(width, height, world, deal[0], deal[1]))

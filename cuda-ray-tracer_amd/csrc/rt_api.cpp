@@ -55,6 +55,7 @@ struct rt_ctx {
     int device = 0;
     bool haveScene = false, haveState = false;
     bool chunksSequential = true;
+    int dealRank0 = 1, dealOther = 1;   // how the tiles of a sharded frame are dealt to the ranks (rt_set_tile_deal)
     rt::DevScene scene{};
     rt::FrameParams frame{};
     rt_scene_info info{};
@@ -137,9 +138,13 @@ constexpr int kMaxOrderedTiles = 1 << 16;   // frames with more tiles per rank a
 
 int tilesAlong(int pixels) { return (pixels + RT_TILE - 1) / RT_TILE; }
 
-int ownedTileCount(int tiles, int rank, int world) {
-    if (rank >= tiles) return 0;
-    return (tiles - rank + world - 1) / world;
+rt::TileDeal dealOf(const rt_ctx* ctx, int world) { return rt::TileDeal{world, ctx->dealRank0, ctx->dealOther}; }
+
+bool validDeal(int rank0Slots, int otherSlots) { return rank0Slots >= 1 && rank0Slots <= 64 && otherSlots >= 1 && otherSlots <= 64; }
+
+// bytes of one rank's tile buffer under the context's deal
+size_t tileBufferBytes(const rt_ctx* ctx, int width, int height, int world) {
+    return rt_tile_buffer_bytes_dealt(width, height, world, ctx->dealRank0, ctx->dealOther);
 }
 
 // The dispatch feedback (tile costs, the tile order ranked from them, the block lists) and the patched scene tables are written
@@ -186,9 +191,10 @@ int checkFrameArgs(rt_ctx* ctx, int width, int height) {
 rt::FrameParams frameFor(const rt_ctx* ctx, int width, int height, int rank, int world, bool compact) {
     rt::FrameParams p = ctx->frame;
     p.width = width; p.height = height;
-    p.rank = rank; p.world = world;
+    const rt::TileDeal deal = dealOf(ctx, world);
+    p.rank = rt::dealFirstSlot(deal, rank); p.world = rt::dealPeriod(deal); p.tileRun = rt::dealRun(deal, rank);
     p.tilesX = tilesAlong(width); p.tilesY = tilesAlong(height);
-    p.ownedTiles = ownedTileCount(p.tilesX * p.tilesY, rank, world);
+    p.ownedTiles = rt::dealOwned(deal, rank, p.tilesX * p.tilesY);
     p.compactOutput = compact ? 1 : 0;
     p.blockOrder = ctx->blockOrder;
     p.nodePoolEntries = ctx->nodePoolEntries;
@@ -211,7 +217,7 @@ DispatchPlan planDispatch(const rt_ctx* ctx, const rt::FrameParams& p) {
     // frame geometry the tile order belongs to: 16 bits each of width and height, 12 bits each of world and rank (wider
     // values only cost a needless restart of the feedback), and the tile count the order list was sized for
     d.key = ((long long)(p.width & 0xffff) << 47) | ((long long)(p.height & 0xffff) << 31) | ((long long)(p.world & 0xfff) << 19) |
-            ((long long)(p.rank & 0xfff) << 7);
+            ((long long)(p.rank & 0xfff) << 7) | (long long)(p.tileRun & 0x7f);
     d.key ^= (long long)p.ownedTiles * 0x9E3779B1LL;
     d.haveOrder = d.ordered && ctx->orderKey == d.key;
     return d;
@@ -787,7 +793,7 @@ int rt_render_path_tiles_device(rt_ctx* ctx, int width, int height, int rank, in
     if (rc) return rc;
     if (world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "rank/world out of range");
     if (!d_tiles) return fail(RT_ERR_INVALID, "null device buffer");
-    if (frame_stride_bytes < rt_tile_buffer_bytes(width, height, world) || frame_stride_bytes % 16 != 0)
+    if (frame_stride_bytes < tileBufferBytes(ctx, width, height, world) || frame_stride_bytes % 16 != 0)
         return fail(RT_ERR_INVALID, "frame stride must be a multiple of 16 and hold a tile buffer");
     return renderPath(ctx, width, height, rank, world, true, n_frames, cams, static_cast<uint8_t*>(d_tiles), frame_stride_bytes,
                       static_cast<hipStream_t>(hip_stream));
@@ -801,11 +807,26 @@ int rt_render_device(rt_ctx* ctx, int width, int height, void* d_rgb, void* hip_
     return launchOrdered(ctx, p, static_cast<uint8_t*>(d_rgb), nullptr, nullptr, nullptr, false, static_cast<hipStream_t>(hip_stream));
 }
 
-size_t rt_tile_buffer_bytes(int width, int height, int world) {
-    if (width <= 0 || height <= 0 || world <= 0) return 0;
-    int tiles = tilesAlong(width) * tilesAlong(height);
-    int perRank = (tiles + world - 1) / world;   // rank 0 owns the most tiles; every rank's buffer has this size
-    return (size_t)perRank * RT_TILE * RT_TILE * 3;
+size_t rt_tile_buffer_bytes_dealt(int width, int height, int world, int rank0_slots, int other_slots) {
+    if (width <= 0 || height <= 0 || world <= 0 || !validDeal(rank0_slots, other_slots)) return 0;
+    const rt::TileDeal deal{world, rank0_slots, other_slots};
+    // every rank's buffer has the size of the largest share
+    return (size_t)rt::dealMostOwned(deal, tilesAlong(width) * tilesAlong(height)) * RT_TILE * RT_TILE * 3;
+}
+
+size_t rt_tile_buffer_bytes(int width, int height, int world) { return rt_tile_buffer_bytes_dealt(width, height, world, 1, 1); }
+
+int rt_set_tile_deal(rt_ctx* ctx, int rank0_slots, int other_slots) {
+    if (!ctx) return fail(RT_ERR_INVALID, "null context");
+    if (!validDeal(rank0_slots, other_slots)) return fail(RT_ERR_INVALID, "slots per period must be 1 .. 64 for rank 0 and for the other ranks");
+    ctx->dealRank0 = rank0_slots; ctx->dealOther = other_slots;
+    return RT_OK;
+}
+
+int rt_get_tile_deal(rt_ctx* ctx, int* rank0_slots, int* other_slots) {
+    if (!ctx || !rank0_slots || !other_slots) return fail(RT_ERR_INVALID, "null argument");
+    *rank0_slots = ctx->dealRank0; *other_slots = ctx->dealOther;
+    return RT_OK;
 }
 
 int rt_render_tiles_device(rt_ctx* ctx, int width, int height, int rank, int world, void* d_tiles, size_t capacity_bytes, void* hip_stream) {
@@ -813,7 +834,7 @@ int rt_render_tiles_device(rt_ctx* ctx, int width, int height, int rank, int wor
     if (rc) return rc;
     if (world <= 0 || rank < 0 || rank >= world) return fail(RT_ERR_INVALID, "rank/world out of range");
     if (!d_tiles) return fail(RT_ERR_INVALID, "null device buffer");
-    if (capacity_bytes < rt_tile_buffer_bytes(width, height, world)) return fail(RT_ERR_CAPACITY, "tile buffer too small");
+    if (capacity_bytes < tileBufferBytes(ctx, width, height, world)) return fail(RT_ERR_CAPACITY, "tile buffer too small");
     rt::FrameParams p = frameFor(ctx, width, height, rank, world, true);
     return launchOrdered(ctx, p, static_cast<uint8_t*>(d_tiles), nullptr, nullptr, nullptr, false, static_cast<hipStream_t>(hip_stream));
 }
@@ -823,8 +844,8 @@ int rt_untile_device(rt_ctx* ctx, int width, int height, int world, const void* 
     if (width <= 0 || height <= 0 || world <= 0) return fail(RT_ERR_INVALID, "bad frame or world size");
     if (!d_gathered || !d_rgb) return fail(RT_ERR_INVALID, "null device buffer");
     RT_HIP(hipSetDevice(ctx->device));
-    RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb), width, height, world, tilesAlong(width),
-                            rt_tile_buffer_bytes(width, height, world), static_cast<hipStream_t>(hip_stream)));
+    RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb), width, height, dealOf(ctx, world), tilesAlong(width),
+                            tileBufferBytes(ctx, width, height, world), static_cast<hipStream_t>(hip_stream)));
     return RT_OK;
 }
 
@@ -833,10 +854,10 @@ int rt_untile_strided_device(rt_ctx* ctx, int width, int height, int world, cons
     if (!ctx) return fail(RT_ERR_INVALID, "null context");
     if (width <= 0 || height <= 0 || world <= 0) return fail(RT_ERR_INVALID, "bad frame or world size");
     if (!d_gathered || !d_rgb) return fail(RT_ERR_INVALID, "null device buffer");
-    if (rank_stride_bytes < rt_tile_buffer_bytes(width, height, world) || rank_stride_bytes % 16 != 0)
+    if (rank_stride_bytes < tileBufferBytes(ctx, width, height, world) || rank_stride_bytes % 16 != 0)
         return fail(RT_ERR_INVALID, "rank stride must be a multiple of 16 and hold a tile buffer");
     RT_HIP(hipSetDevice(ctx->device));
-    RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb), width, height, world, tilesAlong(width),
+    RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb), width, height, dealOf(ctx, world), tilesAlong(width),
                             rank_stride_bytes, static_cast<hipStream_t>(hip_stream)));
     return RT_OK;
 }
@@ -847,12 +868,12 @@ int rt_untile_batch_device(rt_ctx* ctx, int width, int height, int world, const 
     if (width <= 0 || height <= 0 || world <= 0) return fail(RT_ERR_INVALID, "bad frame or world size");
     if (n_frames <= 0 || n_frames > 65535) return fail(RT_ERR_INVALID, "n_frames must be 1 .. 65535");
     if (!d_gathered || !d_rgb_frames) return fail(RT_ERR_INVALID, "null device buffer");
-    const size_t tileBytes = rt_tile_buffer_bytes(width, height, world);
+    const size_t tileBytes = tileBufferBytes(ctx, width, height, world);
     if (frame_stride_bytes < tileBytes || frame_stride_bytes % 16 != 0) return fail(RT_ERR_INVALID, "frame stride must be a multiple of 16 and hold a tile buffer");
     if (rank_stride_bytes % 16 != 0 || rank_stride_bytes < frame_stride_bytes * (size_t)(n_frames - 1) + tileBytes)
         return fail(RT_ERR_INVALID, "rank stride must be a multiple of 16 and hold the tile buffers of all frames");
     RT_HIP(hipSetDevice(ctx->device));
-    RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb_frames), width, height, world, tilesAlong(width),
+    RT_HIP(rt::launchUntile(static_cast<const uint8_t*>(d_gathered), static_cast<uint8_t*>(d_rgb_frames), width, height, dealOf(ctx, world), tilesAlong(width),
                             rank_stride_bytes, static_cast<hipStream_t>(hip_stream), n_frames, frame_stride_bytes));
     return RT_OK;
 }

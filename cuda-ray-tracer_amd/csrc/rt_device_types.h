@@ -96,11 +96,45 @@ struct DevScene {
     float lightCol[3];
 };
 
+// How the tiles of a frame (row-major over the tile grid) are dealt to the ranks of a sharded run: in periods of
+// rank0Slots + (world - 1) * otherSlots consecutive tiles, of which the first rank0Slots belong to rank 0, the next otherSlots
+// to rank 1, and so on.  1 / 1: tile i belongs to rank i % world.  Rank 0 also reassembles every frame; with fewer slots than
+// the others it renders less, by the time that takes.
+struct TileDeal {
+    int32_t world, rank0Slots, otherSlots;
+};
+#if defined(__HIPCC__)
+#define RT_HOST_DEVICE __host__ __device__
+#else
+#define RT_HOST_DEVICE
+#endif
+RT_HOST_DEVICE inline int dealPeriod(TileDeal d) { return d.rank0Slots + (d.world - 1) * d.otherSlots; }
+RT_HOST_DEVICE inline int dealFirstSlot(TileDeal d, int rank) { return rank == 0 ? 0 : d.rank0Slots + (rank - 1) * d.otherSlots; }
+RT_HOST_DEVICE inline int dealRun(TileDeal d, int rank) { return rank == 0 ? d.rank0Slots : d.otherSlots; }
+// tiles of a frame of `tiles` tiles that belong to `rank`: its local tiles 0 .. count - 1, in frame order
+RT_HOST_DEVICE inline int dealOwned(TileDeal d, int rank, int tiles) {
+    const int period = dealPeriod(d), run = dealRun(d, rank), rest = tiles % period - dealFirstSlot(d, rank);
+    return (tiles / period) * run + (rest < 0 ? 0 : (rest > run ? run : rest));
+}
+RT_HOST_DEVICE inline int dealMostOwned(TileDeal d, int tiles) {
+    const int a = dealOwned(d, 0, tiles), b = d.world > 1 ? dealOwned(d, 1, tiles) : 0;     // ranks 1.. own no more than rank 1
+    return a > b ? a : b;
+}
+// which rank a tile belongs to, and which of that rank's tiles it is
+RT_HOST_DEVICE inline void dealLocate(TileDeal d, uint32_t tile, uint32_t& rank, uint32_t& local) {
+    const uint32_t period = (uint32_t)dealPeriod(d), p = tile / period, s = tile - p * period;
+    if (s < (uint32_t)d.rank0Slots) { rank = 0; local = p * (uint32_t)d.rank0Slots + s; return; }
+    const uint32_t q = s - (uint32_t)d.rank0Slots, r = q / (uint32_t)d.otherSlots;
+    rank = 1u + r; local = p * (uint32_t)d.otherSlots + (q - r * (uint32_t)d.otherSlots);
+}
+
 // Per-frame state handed to the render kernel by value.
 struct FrameParams {
     int32_t width, height;
-    // tile sharding: this launch renders tiles rank, rank + world, ... ; tilesX/tilesY = tile grid
-    int32_t rank, world, tilesX, tilesY, ownedTiles;
+    // tile sharding: of every `world` consecutive tiles (a period of the deal, see TileDeal) this launch renders the `tileRun`
+    // tiles that start at slot `rank`; plain interleaving: rank = the rank, world = the number of ranks, tileRun = 1.
+    // tilesX/tilesY = tile grid
+    int32_t rank, world, tileRun, tilesX, tilesY, ownedTiles;
     int32_t compactOutput;     // 1: write tile-major into the rank's compact buffer, 0: row-major full frame
     int32_t blockOrder;        // workgroup -> tile mapping: 0 tile by tile, 2 tiles interleaved over the XCDs
     int32_t nodePoolEntries;   // low half: capacity of the traversal's pool of pending children that a wave may use (96 .. the compiled size), high half: of its pool of triangle work (72 .. compiled size); 0 = compiled size, smaller values only serve tests

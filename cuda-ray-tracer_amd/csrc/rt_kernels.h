@@ -48,7 +48,7 @@ struct StaticScratch { uint32_t* words; int costSlot; long long orderKey; std::m
 // Looks the array's address up on first use per device (which must be the current device) and returns that device's record.
 hipError_t staticScratch(int device, StaticScratch** out);
 
-hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX,
+hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, TileDeal deal, int tilesX,
                         size_t perRankBytes, hipStream_t stream, int frames = 1, size_t frameStrideIn = 0);
 
 }  // namespace rt

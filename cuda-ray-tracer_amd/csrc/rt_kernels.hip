@@ -1272,7 +1272,9 @@ __global__ __launch_bounds__(kBlockThreads) __attribute__((amdgpu_waves_per_eu(R
     // from it is scalar)
     localTile = (uint32_t)__builtin_amdgcn_readfirstlane((int)localTile); inTile = (uint32_t)__builtin_amdgcn_readfirstlane((int)inTile);
     sub = (uint32_t)__builtin_amdgcn_readfirstlane((int)sub);
-    const uint32_t tile = localTile * (uint32_t)P.world + (uint32_t)P.rank;
+    // (plain interleaving, one tile per period, needs no division)
+    const uint32_t run = (uint32_t)P.tileRun, period = run > 1u ? localTile / run : localTile;
+    const uint32_t tile = period * (uint32_t)P.world + (uint32_t)P.rank + (localTile - period * run);
     const uint32_t tileX = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile % (uint32_t)P.tilesX)), tileY = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tile / (uint32_t)P.tilesX));
     // the waves of a tile walk it in Z order (neighbours in time are neighbours on screen).  A regular wave renders the whole
     // 8x8 block, lane l = pixel (l & 7, l >> 3); a split wave renders row `sub` of the block with its first eight lanes.
@@ -1388,11 +1390,11 @@ __global__ __launch_bounds__(64) void rankTilesKernel(const uint32_t* __restrict
     if (lane == 0) { order[rank] = (uint32_t)i; clearNext[i] = 0; }
 }
 
-// Tile-major buffers of `world` ranks laid end to end -> row-major frame.  One thread per 4 output bytes.
+// Tile-major buffers of the ranks of a deal laid end to end -> row-major frame.  One thread per 4 output bytes.
 // (All three reassembly kernels: blockIdx.y = frame of a batch; frame f reads from gathered + f * frameStrideIn and writes the
 // f-th of consecutive frames.)
 __global__ __launch_bounds__(256) void untileKernel(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ out, int width, int height,
-                                                    int world, int tilesX, size_t perRankBytes, size_t frameStrideIn) {
+                                                    TileDeal deal, int tilesX, size_t perRankBytes, size_t frameStrideIn) {
     const size_t total = (size_t)width * (size_t)height * 3;
     gathered += (size_t)blockIdx.y * frameStrideIn; out += (size_t)blockIdx.y * total;
     const size_t i4 = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
@@ -1404,7 +1406,8 @@ __global__ __launch_bounds__(256) void untileKernel(const uint8_t* __restrict__ 
         size_t pix = i / 3; int ch = (int)(i % 3);
         int x = (int)(pix % (size_t)width), y = (int)(pix / (size_t)width);
         int tile = (y / RT_TILE_PX) * tilesX + (x / RT_TILE_PX);
-        int rank = tile % world, local = tile / world;
+        uint32_t rank, local;
+        dealLocate(deal, (uint32_t)tile, rank, local);
         size_t src = (size_t)rank * perRankBytes + ((size_t)local * (RT_TILE_PX * RT_TILE_PX) + (size_t)(y % RT_TILE_PX) * RT_TILE_PX + (x % RT_TILE_PX)) * 3 + ch;
         v[k] = gathered[src];
     }
@@ -1424,7 +1427,7 @@ __global__ __launch_bounds__(256) void untileKernel(const uint8_t* __restrict__ 
 // neighbour's, reached 2.2 TB/s.
 constexpr uint32_t kUntilePieces = 6;
 __global__ __launch_bounds__(256) void untilePiecesKernel(const uint8_t* __restrict__ gathered, uint8_t* __restrict__ out, int width, int height,
-                                                          int world, int tilesX, size_t perRankBytes, size_t frameStrideIn) {
+                                                          TileDeal deal, int tilesX, size_t perRankBytes, size_t frameStrideIn) {
     const uint32_t piecesPerRow = (uint32_t)width * 3 / 16, pieces = piecesPerRow * (uint32_t)height;
     gathered += (size_t)blockIdx.y * frameStrideIn; out += (size_t)blockIdx.y * (size_t)pieces * 16;
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / 64, lane = threadIdx.x % 64;
@@ -1436,7 +1439,8 @@ __global__ __launch_bounds__(256) void untilePiecesKernel(const uint8_t* __restr
         if (piece >= pieces) break;
         const uint32_t y = piece / piecesPerRow, xp = piece - y * piecesPerRow;
         const uint32_t tile = (y / RT_TILE_PX) * (uint32_t)tilesX + xp / kTileRowPieces;
-        const uint32_t rank = tile % (uint32_t)world, local = tile / (uint32_t)world;
+        uint32_t rank, local;
+        dealLocate(deal, tile, rank, local);
         const size_t src = (size_t)rank * perRankBytes + ((size_t)local * (RT_TILE_PX * kTileRowPieces) + (size_t)(y % RT_TILE_PX) * kTileRowPieces + xp % kTileRowPieces) * 16;
         v[k] = __builtin_nontemporal_load(reinterpret_cast<const u4_t*>(gathered + src));
     }
@@ -1671,7 +1675,7 @@ hipError_t staticScratch(int device, StaticScratch** out) {
     return hipSuccess;
 }
 
-hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, int world, int tilesX, size_t perRankBytes,
+hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int height, TileDeal deal, int tilesX, size_t perRankBytes,
                         hipStream_t stream, int frames, size_t frameStrideIn) {
     size_t total = (size_t)width * (size_t)height * 3;
     if (frames <= 0) return hipSuccess;
@@ -1680,12 +1684,12 @@ hipError_t launchUntile(const uint8_t* gathered, uint8_t* out, int width, int he
                          (frames == 1 || (frameStrideIn % 16 == 0 && total % 16 == 0));
     if (aligned && width % 16 == 0 && total / 16 < (1ull << 31)) {
         const size_t waves = (total / 16 + 64 * kUntilePieces - 1) / (64 * kUntilePieces);
-        hipLaunchKernelGGL(untilePiecesKernel, dim3((unsigned)((waves + 3) / 4), (unsigned)frames), dim3(256), 0, stream, gathered, out, width, height, world, tilesX, perRankBytes, frameStrideIn);
+        hipLaunchKernelGGL(untilePiecesKernel, dim3((unsigned)((waves + 3) / 4), (unsigned)frames), dim3(256), 0, stream, gathered, out, width, height, deal, tilesX, perRankBytes, frameStrideIn);
         return hipGetLastError();
     }
     size_t threads = (total + 3) / 4;
     dim3 grid((unsigned)((threads + 255) / 256), (unsigned)frames), block(256);
-    hipLaunchKernelGGL(untileKernel, grid, block, 0, stream, gathered, out, width, height, world, tilesX, perRankBytes, frameStrideIn);
+    hipLaunchKernelGGL(untileKernel, grid, block, 0, stream, gathered, out, width, height, deal, tilesX, perRankBytes, frameStrideIn);
     return hipGetLastError();
 }
 

@@ -97,7 +97,9 @@ int rt_gather_tiles(rt_comm* c, const void* d_tiles, size_t bytes_per_rank, void
 int rt_render_frame_sharded(rt_ctx* ctx, rt_comm* c, int width, int height, uint8_t* rgb_out) {
     if (!ctx || !c) return fail(RT_ERR_INVALID, "null argument");
     if (c->rank == 0 && !rgb_out) return fail(RT_ERR_INVALID, "rank 0 needs an output buffer");
-    const size_t per = rt_tile_buffer_bytes(width, height, c->world);
+    int rank0Slots = 1, otherSlots = 1;      // the context's deal of the tiles (rt_set_tile_deal), the same on every rank
+    if (rt_get_tile_deal(ctx, &rank0Slots, &otherSlots) != RT_OK) return fail(RT_ERR_INVALID, rt_last_error());
+    const size_t per = rt_tile_buffer_bytes_dealt(width, height, c->world, rank0Slots, otherSlots);
     if (per == 0) return fail(RT_ERR_INVALID, "bad frame size");
     RT_TRY_HIP(hipSetDevice(c->device));
     // What can fail on this rank alone (an allocation, the render call's own checks) must not keep it out of the collectives:

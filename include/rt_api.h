@@ -147,8 +147,22 @@ int rt_render_path_tiles_device(rt_ctx* ctx, int width, int height, int rank, in
 size_t rt_tile_buffer_bytes(int width, int height, int world);
 
 /*
+ * How the tiles of a sharded frame are dealt to the ranks, a setting of the context that the tile entry points below read
+ * (rt_render_tiles_device, rt_render_path_tiles_device, rt_untile_device, rt_untile_strided_device, rt_untile_batch_device):
+ * tiles are dealt in periods of rank0_slots + (world - 1) * other_slots consecutive tiles, of which the first rank0_slots go
+ * to rank 0, the next other_slots to rank 1, and so on; a rank's buffer holds its tiles in frame order.  The default, 1 / 1,
+ * is tile i -> rank i % world.  Rank 0 reassembles every frame besides rendering its share: with 4 / 5 on eight GPUs it
+ * renders 4/39 of the tiles instead of 1/8 and the others 5/39 each.  Every rank of a run, and the context that reassembles,
+ * must use the same deal; buffers then need rt_tile_buffer_bytes_dealt bytes (the largest share).  Slots: 1 .. 64.
+ * No reference counterpart (the reference is single-GPU).
+ */
+int rt_set_tile_deal(rt_ctx* ctx, int rank0_slots, int other_slots);
+int rt_get_tile_deal(rt_ctx* ctx, int* rank0_slots, int* other_slots);
+size_t rt_tile_buffer_bytes_dealt(int width, int height, int world, int rank0_slots, int other_slots);
+
+/*
  * Renders only the RT_TILE x RT_TILE tiles owned by `rank` (tile i, row-major over the tile grid, belongs to
- * rank i % world) into d_tiles, compactly: the rank's j-th tile occupies bytes [j*3*RT_TILE^2, (j+1)*3*RT_TILE^2),
+ * rank i % world, or to the rank that rt_set_tile_deal's periods give it) into d_tiles, compactly: the rank's j-th tile occupies bytes [j*3*RT_TILE^2, (j+1)*3*RT_TILE^2),
  * row-major inside the tile, edge tiles padded.  No reference counterpart (the reference is single-GPU).
  */
 int rt_render_tiles_device(rt_ctx* ctx, int width, int height, int rank, int world, void* d_tiles,

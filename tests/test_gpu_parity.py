@@ -101,11 +101,11 @@ def test_octree_shape_does_not_change_pixels(renderer, oracle, leaf, depth):
     assert st.rays == st0.rays
 
 
-def _render_tiles_emulated(renderer, w, h, world):
+def _render_tiles_emulated(renderer, w, h, world, deal=(1, 1)):
     """One GPU plays every rank in turn: renders each rank's tiles into its slot of a gathered buffer, then untiles."""
     import torch
     from cuda_ray_tracer_amd import binding
-    per = binding.tile_buffer_bytes(w, h, world)
+    per = binding.tile_buffer_bytes(w, h, world, deal)
     gathered = torch.zeros(per * world, dtype=torch.uint8, device="cuda:0")
     frame = torch.zeros(w * h * 3, dtype=torch.uint8, device="cuda:0")
     stream = torch.cuda.current_stream().cuda_stream
@@ -129,6 +129,48 @@ def test_tile_sharded_frame_equals_single_gpu_frame(renderer, world, size):
     direct, _ = renderer.render(w, h)
     tiled = _render_tiles_emulated(renderer, w, h, world)
     assert np.array_equal(direct, tiled)
+
+
+@pytest.mark.parametrize("world,deal", [(2, (2, 3)), (3, (1, 4)), (8, (4, 5)), (8, (3, 3)), (4, (6, 7)), (1, (2, 5))])
+@pytest.mark.parametrize("size", [(640, 360), (333, 201)])
+def test_frame_sharded_with_a_lighter_share_for_rank_zero(renderer, world, deal, size):
+    """rt_set_tile_deal: tiles dealt in periods in which rank 0 owns fewer slots than the others.  Every rank's buffer holds
+    exactly the tiles the numpy statement of the layout gives it, and the reassembled frame is the one-launch frame."""
+    import torch
+    from cuda_ray_tracer_amd import binding, sharding
+    w, h = size
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.2)
+    built = scenes.build_scene(spec)
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    direct, _ = renderer.render(w, h)
+    renderer.set_tile_deal(*deal)
+    try:
+        tiled = _render_tiles_emulated(renderer, w, h, world, deal)
+        assert np.array_equal(direct, tiled)
+        per = binding.tile_buffer_bytes(w, h, world, deal)
+        assert per == sharding.tile_buffer_bytes(w, h, world, deal)
+        buf = torch.zeros(per, dtype=torch.uint8, device="cuda:0")
+        for rank in sorted({0, world - 1}):
+            buf.zero_()
+            renderer.render_tiles_device(w, h, rank, world, buf.data_ptr(), per, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            expect = sharding.tile_numpy(direct, rank, world, deal)
+            got = buf.cpu().numpy()
+            tiles = len(sharding.owned_tiles(w, h, rank, world, deal))
+            # (edge tiles: the kernel leaves the padding of its buffer alone, the numpy statement zeroes it: both are zero here)
+            assert np.array_equal(got[:tiles * 32 * 32 * 3], expect[:tiles * 32 * 32 * 3])
+    finally:
+        renderer.set_tile_deal(1, 1)
+
+
+def test_tile_deal_arguments_are_checked(renderer):
+    from cuda_ray_tracer_amd import binding
+    for bad in [(0, 1), (1, 0), (65, 1), (1, 65), (-1, 3)]:
+        with pytest.raises(binding.RtError):
+            renderer.set_tile_deal(*bad)
+        assert binding.tile_buffer_bytes(640, 360, 4, bad) == 0
+    renderer.set_tile_deal(1, 1)
 
 
 def test_render_device_matches_host_entry_point(renderer):
