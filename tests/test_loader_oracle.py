@@ -204,3 +204,24 @@ def test_string_helpers_follow_the_reference():
     assert ref.split("a  b", " ") == ["a", "", "b"]                          # OBJ_Loader.h:213-216: an empty entry per extra blank
     assert ref.tail("  usemtl   Gold leaf \t") == "Gold leaf" and ref.tail("g") == "" and ref.first_token("\tvn 0 0 1") == "vn"
     assert ref.first_token("") == "" and ref.tail("") == ""
+
+
+def test_mutated_files_never_take_the_loader_outside_its_memory(tmp_path):
+    """tools/loader_fuzz.cpp under AddressSanitizer + UBSan (host code only): truncated files, flipped bytes, dropped and doubled
+    lines, face indices far out of range, non-numbers, missing material libraries - the loader returns, and every index it
+    reports points into the vertices it reports."""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = tmp_path / "loader_fuzz"
+    host = os.path.join(ROOT, "cuda-ray-tracer_amd", "host")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-I" + host,
+                    os.path.join(ROOT, "tools", "loader_fuzz.cpp"), os.path.join(host, "OBJ_Loader.cpp"), "-o", str(exe)], check=True, timeout=300)
+    scratch = tmp_path / "scratch"
+    scratch.mkdir()
+    models = [os.path.join(ROOT, "assets", "models", n) for n in ("cube.obj", "Table.obj", "Book2_Open.obj")]
+    env = dict(os.environ, FUZZ_ROUNDS="30")
+    out = subprocess.run([str(exe), str(scratch)] + models, capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    assert "none left the loader's own memory" in out.stdout
