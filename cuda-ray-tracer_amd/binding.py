@@ -38,6 +38,7 @@ def lib():
     L.rt_upload_scene.argtypes = [vp, C.POINTER(T.SceneDesc)]
     L.rt_update_frame_state.argtypes = [vp, C.POINTER(T.Camera), C.POINTER(T.Config), C.POINTER(T.Dynamic)]
     L.rt_set_strict_octree_flag.argtypes = [vp, i32]
+    L.rt_update_objects.argtypes = [vp, C.POINTER(T.SceneDesc)]
     L.rt_render_frame.argtypes = [vp, i32, i32, vp, C.POINTER(T.FrameStats)]
     L.rt_render_frame_ids.argtypes = [vp, i32, i32, vp, vp, vp, C.POINTER(T.FrameStats)]
     L.rt_render_device.argtypes = [vp, i32, i32, vp, vp]
@@ -103,6 +104,10 @@ class Renderer:
 
     def upload(self, scene_desc):
         _check(lib().rt_upload_scene(self._ctx, C.byref(scene_desc)))
+
+    def update_objects(self, scene_desc):
+        """Replaces spheres, planes, boxes and the light; the uploaded models stay (rt_update_objects)."""
+        _check(lib().rt_update_objects(self._ctx, C.byref(scene_desc)))
 
     def set_state(self, camera, config, dynamic=None):
         _check(lib().rt_update_frame_state(self._ctx, C.byref(camera), C.byref(config),

@@ -550,6 +550,53 @@ int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene) {
     return RT_OK;
 }
 
+int rt_update_objects(rt_ctx* ctx, const rt_scene_desc* scene) {
+    if (!ctx || !scene) return fail(RT_ERR_INVALID, "null argument");
+    if (!ctx->haveScene) return fail(RT_ERR_NO_SCENE, "rt_upload_scene has not been called");
+    rt_scene_desc only = *scene;           // the tables of spheres, planes and boxes and the light; the uploaded meshes stay
+    only.models = nullptr; only.modelCount = 0;
+    rt::FlatScene flat;
+    std::string err;
+    if (!rt::flattenScene(only, flat, err, false)) return fail(RT_ERR_INVALID, err);
+
+    RT_HIP(hipSetDevice(ctx->device));
+    RT_HIP(hipDeviceSynchronize());        // launches that still read the old tables
+    rt::DevScene d = ctx->scene;
+    std::vector<void*> fresh;
+    int64_t bytes = 0;
+    int rc = 0;
+    if ((rc = uploadArray(flat.sphGeom, &d.sphGeom, fresh, bytes)) || (rc = uploadArray(flat.sphMat, &d.sphMat, fresh, bytes)) ||
+        (rc = uploadArray(flat.plnP, &d.plnP, fresh, bytes)) || (rc = uploadArray(flat.plnN, &d.plnN, fresh, bytes)) ||
+        (rc = uploadArray(flat.plnMat, &d.plnMat, fresh, bytes)) || (rc = uploadArray(flat.plnNormals, &d.plnNormals, fresh, bytes)) ||
+        (rc = uploadArray(flat.boxMin, &d.boxMin, fresh, bytes)) || (rc = uploadArray(flat.boxMax, &d.boxMax, fresh, bytes)) ||
+        (rc = uploadArray(flat.boxMat, &d.boxMat, fresh, bytes))) {
+        for (void* p : fresh) (void)hipFree(p);       // the context keeps the scene it had
+        return rc;
+    }
+    const void* old[9] = {ctx->scene.sphGeom, ctx->scene.sphMat, ctx->scene.plnP, ctx->scene.plnN, ctx->scene.plnMat, ctx->scene.plnNormals,
+                          ctx->scene.boxMin, ctx->scene.boxMax, ctx->scene.boxMat};
+    int64_t oldBytes = ((int64_t)ctx->scene.nSph * 4 + (int64_t)ctx->scene.nPln * (5 + 5) + (int64_t)ctx->scene.nBox * 5) * (int64_t)sizeof(rt::F4);
+    auto& A = ctx->sceneAllocs;
+    for (const void* o : old) {
+        if (!o) continue;
+        for (size_t i = 0; i < A.size(); i++) if (A[i] == o) { (void)hipFree(A[i]); A.erase(A.begin() + (long)i); break; }
+    }
+    A.insert(A.end(), fresh.begin(), fresh.end());
+    d.nSph = scene->sphereCount; d.nPln = scene->planeCount; d.nBox = scene->AABBCount;
+    std::memcpy(d.lightPos, flat.lightPos, sizeof d.lightPos);
+    std::memcpy(d.lightCol, flat.lightCol, sizeof d.lightCol);
+    ctx->scene = d;
+    ctx->hasSphere0 = !flat.sphGeom.empty();
+    if (ctx->hasSphere0) ctx->sphere0Geom = flat.sphGeom[0];
+    ctx->hasPlane0 = !flat.plnMat.empty();
+    if (ctx->hasPlane0) ctx->plane0Mat0 = flat.plnMat[0];
+    ctx->sphere0Dirty = ctx->plane0Dirty = false;
+    rt_scene_info& in = ctx->info;
+    in.sphereCount = d.nSph; in.planeCount = d.nPln; in.AABBCount = d.nBox;
+    in.deviceBytes += bytes - oldBytes;
+    return RT_OK;
+}
+
 int rt_validate_scene_device(rt_ctx* ctx, const rt_scene_desc* scene) {
     if (!ctx || !scene) return fail(RT_ERR_INVALID, "null argument");
     if (!ctx->haveScene) return fail(RT_ERR_NO_SCENE, "rt_upload_scene has not been called");

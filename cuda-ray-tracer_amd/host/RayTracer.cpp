@@ -162,31 +162,31 @@ void RayTracer::initialiseScenes() {
         finish(s);
     }
     scene = scenes[0];
-    sceneDirty_ = true;
+    sceneDirty_ = kSceneEverything;
 }
 
 void RayTracer::switchScene(int sceneNum) {
     if (sceneNum < 0 || sceneNum >= sceneCount) return;
     scene = scenes[(size_t)sceneNum];
-    sceneDirty_ = true;
+    sceneDirty_ = kSceneEverything;
 }
 
 void RayTracer::addSphere(vec3 pos, float radius, Material m, ObjectType objectType) {
     scene.spheres.push_back(Sphere(pos, radius, m, false, objectType));
     scene.sphereCount = (int)scene.spheres.size();
-    sceneDirty_ = true;
+    if (sceneDirty_ == kSceneSame) sceneDirty_ = kSceneObjects;      // the meshes on the GPU stay
 }
 
 void RayTracer::addPlane(vec3 pos, vec3 n, Material m, ObjectType objectType) {
     scene.planes.push_back(Plane(pos, n, m, false, objectType));
     scene.planeCount = (int)scene.planes.size();
-    sceneDirty_ = true;
+    if (sceneDirty_ == kSceneSame) sceneDirty_ = kSceneObjects;      // the meshes on the GPU stay
 }
 
 void RayTracer::addAABB(vec3 pos, float size, Material m, ObjectType objectType) {
     scene.AABBs.push_back(AABB(pos, size, m, false, objectType));
     scene.AABBCount = (int)scene.AABBs.size();
-    sceneDirty_ = true;
+    if (sceneDirty_ == kSceneSame) sceneDirty_ = kSceneObjects;      // the meshes on the GPU stay
 }
 
 void describeScene(const Scene& scene, rt_scene_desc& out, SceneDescStorage& st) {
@@ -222,7 +222,7 @@ void RayTracer::launchKernel() {
         std::cerr << "HIP Error: " << rt_last_error() << " at " << __FILE__ << ", line: " << __LINE__ << std::endl;
         return;
     }
-    sceneDirty_ = false;
+    sceneDirty_ = kSceneSame;
     lastGpuMs = stats.gpu_ms;
     lastRayCount = stats.rays;
 }

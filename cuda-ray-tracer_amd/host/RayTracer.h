@@ -19,6 +19,11 @@ typedef unsigned char GLubyte;   // the framebuffer element type of the referenc
 
 // RayTracer.h:17-34.  Arrays are std::vectors; the count members mirror the reference's fields and are kept in
 // step by RayTracer (scene.spheres[i], scene.sphereCount etc. read as in the reference).
+// What changed in the scene arrays since the previous call: nothing; only the tables of spheres, planes and boxes or the light's
+// colour (addSphere / addPlane / addAABB, RayTracer.cpp:360-403: the meshes on the GPU stay, rt_update_objects); or anything else
+// (a scene switch, a model: everything is flattened and uploaded again, rt_upload_scene).
+enum SceneChange { kSceneSame = 0, kSceneObjects = 1, kSceneEverything = 2 };
+
 struct Scene {
     std::vector<Sphere> spheres;  int sphereCount = 0;
     std::vector<Plane> planes;    int planeCount = 0;
@@ -112,6 +117,6 @@ public:
 
 private:
     rt_ctx* ctx_ = nullptr;
-    bool sceneDirty_ = true;
+    SceneChange sceneDirty_ = kSceneEverything;      // what of the scene arrays the next frame has to hand to the GPU
     std::vector<GLubyte> frameStorage_;
 };

@@ -24,10 +24,10 @@ void rayTraceShutdown();
 
 // What rayTrace does before it renders: uploads the scene arrays if they changed and hands over everything that travels with
 // a frame (camera, configuration, light, spheres[0], planes[0] ambient colour).  Returns an rt_status.
-int prepareFrame(rt_ctx* ctx, const Scene& scene, const SceneConfig& config, bool sceneChanged);
+int prepareFrame(rt_ctx* ctx, const Scene& scene, const SceneConfig& config, SceneChange sceneChanged);
 
-// Renders `scene` under `config` into framebuffer (width * height * 3 bytes).  sceneChanged: the scene arrays were
+// Renders `scene` under `config` into framebuffer (width * height * 3 bytes).  sceneChanged: how the scene arrays were
 // replaced or resized since the previous call (a scene switch or an add*); the per-frame mutable members (light,
 // spheres[0], planes[0] ambient colour, camera, config) are always re-read.  Returns an rt_status.
 int rayTrace(rt_ctx* ctx, int width, int height, GLubyte* framebuffer, const Scene& scene, const SceneConfig& config,
-             bool sceneChanged, rt_frame_stats* stats = nullptr);
+             SceneChange sceneChanged, rt_frame_stats* stats = nullptr);

@@ -72,6 +72,15 @@ void rt_destroy(rt_ctx* ctx);
 int rt_upload_scene(rt_ctx* ctx, const rt_scene_desc* scene);
 
 /*
+ * Replaces the spheres, planes, boxes and the light of the uploaded scene by those of `scene` and leaves the uploaded models -
+ * their triangles, attributes and octrees - where they are (scene->models is not read).  This is what addSphere / addPlane /
+ * addAABB (RayTracer.cpp:360-403: reallocate the one table, copy, append) cost in the reference; a full rt_upload_scene after
+ * such a call would flatten every mesh again.  Blocks until launches that read the old tables have finished.  On failure the
+ * context keeps the scene it had.
+ */
+int rt_update_objects(rt_ctx* ctx, const rt_scene_desc* scene);
+
+/*
  * Sets what the reference passes by value on every launch (Scene::cam and SceneConfig, kernels.h:11) plus the
  * scene members its frame loop rewrites between launches (Window.cpp:357-384).  dyn may be NULL.
  */

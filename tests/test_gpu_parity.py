@@ -451,3 +451,64 @@ def test_batched_untile_reassembles_every_frame_of_a_gather(renderer, size):
     assert not np.array_equal(direct[0], direct[1])
     with pytest.raises(binding.RtError):
         renderer.untile_batch_device(w, h, world, gathered.data_ptr(), (frames - 1) * per, per, frames, out.data_ptr(), stream)   # rank stride too small for three frames
+
+
+def test_update_objects_equals_a_full_upload_and_leaves_the_meshes_alone(renderer, oracle):
+    """rt_update_objects (the reference's addSphere / addPlane / addAABB, RayTracer.cpp:360-403): new tables of spheres, planes and
+    boxes and a new light colour over the meshes that are already on the GPU = the frame, the ids and the distances of a context
+    that uploaded the whole new scene, and = the oracle; a rejected update leaves the scene as it was."""
+    import copy
+    from cuda_ray_tracer_amd import binding
+    from cuda_ray_tracer_amd import ctypes_types as T
+    w, h = 320, 180
+    spec, cfg, _, _ = scenes.config_scene(3, detail=0.2)
+    built = scenes.build_scene(spec)
+    renderer.upload(built.desc)
+    renderer.set_state(built.camera, cfg)
+    before, _ = renderer.render(w, h)
+    info_before = renderer.scene_info()
+
+    spec2 = copy.deepcopy(spec)
+    green = ((0.0, 1.0, 0.0), (0.0, 1.0, 0.0), 0.2, 0.8, 0.5, 50.0)
+    spec2.spheres.append(((5.0, 0.0, -30.0), 4.0, green, False, T.RT_REFLECT))
+    spec2.spheres.append(((-12.0, 8.0, -40.0), 3.0, green, False, T.RT_DIFFUSE))
+    spec2.boxes.append(((10.0, 10.0, -45.0), 6.0, green, False, T.RT_REFLECT))
+    spec2.planes.append(((0.0, 0.0, -120.0), (0.0, 0.0, 1.0), scenes.FLOOR, T.RT_DIFFUSE))
+    spec2.light_colour = (1.0, 0.9, 0.7)
+    built2 = scenes.build_scene(spec2)
+    renderer.update_objects(built2.desc)
+    renderer.set_state(built2.camera, cfg)
+    rgb, ids, t, st = renderer.render_ids(w, h)
+    info = renderer.scene_info()
+    assert (info.sphereCount, info.planeCount, info.AABBCount) == (len(spec2.spheres), len(spec2.planes), len(spec2.boxes))
+    assert (info.modelCount, info.triangleCount, info.nodeCount) == (info_before.modelCount, info_before.triangleCount, info_before.nodeCount)
+    assert not np.array_equal(rgb, before)
+
+    fresh = binding.Renderer(0)
+    fresh.upload(built2.desc)
+    fresh.set_state(built2.camera, cfg)
+    rgb_f, ids_f, t_f, st_f = fresh.render_ids(w, h)
+    assert np.array_equal(rgb, rgb_f) and np.array_equal(ids, ids_f) and np.array_equal(t.view(np.uint32), t_f.view(np.uint32)) and st.rays == st_f.rays
+    assert fresh.scene_info().deviceBytes == info.deviceBytes
+    o_rgb, o_ids, o_t, o_rays, _ = oracle.render(built2.desc, built2.camera, cfg, w, h, threads=16)
+    assert np.array_equal(ids, o_ids) and np.array_equal(t.view(np.uint32), o_t.view(np.uint32)) and st.rays == o_rays
+    assert int(np.abs(rgb.astype(np.int16) - o_rgb.astype(np.int16)).max()) <= 1
+
+    # fewer objects than before, then a rejected update
+    spec3 = copy.deepcopy(spec)
+    spec3.spheres = []
+    built3 = scenes.build_scene(spec3)
+    renderer.update_objects(built3.desc)
+    renderer.set_state(built3.camera, cfg)
+    none_rgb, _ = renderer.render(w, h)
+    fresh.upload(built3.desc)
+    fresh.set_state(built3.camera, cfg)
+    assert np.array_equal(none_rgb, fresh.render(w, h)[0])
+    built2.desc.lightCount = 0
+    with pytest.raises(binding.RtError, match="light"):
+        renderer.update_objects(built2.desc)
+    assert np.array_equal(renderer.render(w, h)[0], none_rgb)
+    empty = binding.Renderer(0)
+    built2.desc.lightCount = 1
+    with pytest.raises(binding.RtError):
+        empty.update_objects(built2.desc)            # nothing uploaded yet
