@@ -95,6 +95,10 @@ RT_DEV float selMax(float x, float y) { return (x > y) ? x : y; }   // utils.h:9
 RT_DEV float selMin(float x, float y) { return (x < y) ? x : y; }   // utils.h:86-88
 
 RT_DEV f4_t ld4(const F4* p) { return *reinterpret_cast<const f4_t*>(p); }
+typedef float f3_t __attribute__((ext_vector_type(3)));
+// The first three words of a record whose fourth is not needed: a 12-byte request, and no register that waits for a word
+// nobody reads (the code after the loads would reuse such a register at once, and wait for the load to do so).
+RT_DEV f3_t ld3(const F4* p) { return *reinterpret_cast<const f3_t*>(p); }
 // Loads at an address that is the same for the whole wave, from tables nothing writes while a render kernel runs (the scene's
 // object tables): through the constant address space, so that the scalar unit fetches them (its cache holds these few hundred
 // bytes for good, and the values arrive in scalar registers) instead of 64 lanes asking the vector cache for one address.
@@ -238,6 +242,19 @@ RT_DEV Mat loadMat(const F4* base, int idx) {
     f4_t a = ld4(base + 3 * idx), b = ld4(base + 3 * idx + 1), c = ld4(base + 3 * idx + 2);
     Mat m;
     m.ka = xyz(a); m.ambient = a.w; m.kd = xyz(b); m.diffuse = b.w;
+    m.specular = c.x; m.shininess = c.y; m.type = fbits(c.z); m.flags = fbits(c.w);
+    return m;
+}
+
+// A model's material without its two colours, which the hit's interpolated vertex colours replace (kernels.cu:114-117): only
+// the words that are read are requested, so that no register waits for a colour nobody looks at (it would be handed to the
+// address of the attribute fetch that follows, and that fetch would wait for the material).
+RT_DEV Mat loadMatWithoutColours(const F4* base, int idx) {
+    const float* w = reinterpret_cast<const float*>(base + 3 * idx);
+    const float ambient = w[3], diffuse = w[7];
+    f4_t c = ld4(base + 3 * idx + 2);
+    Mat m;
+    m.ka = mk(0, 0, 0); m.ambient = ambient; m.kd = mk(0, 0, 0); m.diffuse = diffuse;
     m.specular = c.x; m.shininess = c.y; m.type = fbits(c.z); m.flags = fbits(c.w);
     return m;
 }
@@ -541,7 +558,10 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
             const F4* np = nodes + (size_t)visited * kNodeFloat4s;
             u4_t head, meta, qx, qy, qz;      // read by the lanes that loaded them
             if (mine) {
-                head = *reinterpret_cast<const u4_t*>(np); meta = *reinterpret_cast<const u4_t*>(np + 1);
+                head = *reinterpret_cast<const u4_t*>(np);
+                // (three words: the fourth is not read, and a register that waits for it would be handed to the next address
+                // computation, which would then wait for the load)
+                { typedef uint32_t u3_t __attribute__((ext_vector_type(3))); const u3_t m3 = *reinterpret_cast<const u3_t*>(np + 1); meta = u4_t{m3.x, m3.y, m3.z, 0u}; }
                 qx = *reinterpret_cast<const u4_t*>(np + 2); qy = *reinterpret_cast<const u4_t*>(np + 3); qz = *reinterpret_cast<const u4_t*>(np + 4);
             }
             fetchPriority(false);
@@ -680,13 +700,15 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
             if (alive) {
                 const V3 ro = xyz(lds.rayO[owner]), rdir = xyz(lds.rayD[owner]);
                 const F4* tp = tris + (size_t)first * 3;
-                const f4_t A0 = ld4(tp), B0 = ld4(tp + 1), C0 = ld4(tp + 2), A1 = ld4(tp + 3), B1 = ld4(tp + 4), C1 = ld4(tp + 5);
+                // (a record's second float4 ends with the model index, which only the final hit needs)
+                const f4_t A0 = ld4(tp), C0 = ld4(tp + 2), A1 = ld4(tp + 3), C1 = ld4(tp + 5);
+                const f3_t B0 = ld3(tp + 1), B1 = ld3(tp + 4);
                 fetchPriority(false);
-                auto testTriangle = [&](f4_t A, f4_t B, f4_t C, uint32_t record) {
+                auto testTriangle = [&](f4_t A, f3_t B, f4_t C, uint32_t record) {
                     const uint32_t idw = fbits(A.w);
                     if (STATS) cnt.triTests++;
                     // Moeller-Trumbore exactly as the reference evaluates it (edges were subtracted on the host)
-                    V3 v0 = xyz(A), e1 = xyz(B), e2 = xyz(C);
+                    V3 v0 = xyz(A), e1 = mk(B.x, B.y, B.z), e2 = xyz(C);
                     V3 pvec = cross(rdir, e2);
                     float det = dot(e1, pvec);
                     bool rejected = (cull && det >= -0.01f) || (fabsf(det) <= 0);
@@ -928,7 +950,7 @@ RT_DEV Surface resolveSurface(SceneK& S, V3 o, V3 d, const Closest& h, int renor
         s.mat = loadMat(inGlobal(S.boxMat), h.idx);
         s.normal = boxNormalAt(xyz(ld4(inGlobal(S.boxMin) + h.idx)), xyz(ld4(inGlobal(S.boxMax) + h.idx)), s.point);
     } else {
-        s.mat = loadMat(inGlobal(S.mdlMat), h.idx);
+        s.mat = loadMatWithoutColours(inGlobal(S.mdlMat), h.idx);
         const F4* ap = inGlobal(S.attrs) + (size_t)(uint32_t)h.tri * kAttrFloat4s;
         f4_t a0 = ld4(ap), a1 = ld4(ap + 1), a2 = ld4(ap + 2), a3 = ld4(ap + 3), a4 = ld4(ap + 4), a5 = ld4(ap + 5), a6 = ld4(ap + 6);
         if (STATS) cnt.attrFetches++;
