@@ -328,6 +328,12 @@ RT_DEV SlabRay makeSlabRay(V3 o, V3 d) {
 // for the arithmetic that follows: of the four waves on a SIMD, the one that is about to wait for memory goes first, so its
 // latency runs under the others' arithmetic (measured: frame 1 % shorter on a latency-bound scene, 2.5-3 % on issue-bound ones;
 // any level above 0 does the same, holding it until the ray has arrived from LDS as well costs 3 %).
+// A turn ends with none of its loads outstanding.  They have long arrived by then; but a turn that rejected all its triangles
+// at the first test, or whose entries all belonged to settled rays, never waited for the records it had requested, and the
+// compiler, unable to tell, makes the next turn wait for ALL loads - its own fresh ones included - before the first write to a
+// register such a record was bound for (measured: the second LDS read of the ray sat behind the node loads instead of under them).
+RT_DEV void loadsHaveArrived() { __builtin_amdgcn_s_waitcnt(0x0F70); }      // vmcnt(0), the other counters left alone
+
 RT_DEV void fetchPriority(bool raised) {
     if (raised) __builtin_amdgcn_s_setprio(2); else __builtin_amdgcn_s_setprio(0);
 }
@@ -557,6 +563,7 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
             const uint32_t visited = base + __builtin_popcount(imask & ((1u << ((uint32_t)__builtin_ctz(hits | 0x100u) ^ oct)) - 1u));
             const F4* np = nodes + (size_t)visited * kNodeFloat4s;
             u4_t head, meta, qx, qy, qz;      // read by the lanes that loaded them
+            loadsHaveArrived();               // (the previous turn's: nothing older is outstanding when this turn's loads go out)
             if (mine) {
                 head = *reinterpret_cast<const u4_t*>(np);
                 // (three words: the fourth is not read, and a register that waits for it would be handed to the next address
@@ -661,6 +668,7 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
                 if (has) lds.triPool[triCount + rank] = (unsigned long long)visited | ((unsigned long long)(owner | (chunkMask << 8) | (pend << 16) | (oct << 24) | kLeafSet) << 32);
                 triCount += (uint32_t)__builtin_popcountll(m);
             }
+            loadsHaveArrived();
             timerA.stop(lds, 0);
         } else {
             SectionTimer<TIMED> timerB;
@@ -700,6 +708,7 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
             if (alive) {
                 const V3 ro = xyz(lds.rayO[owner]), rdir = xyz(lds.rayD[owner]);
                 const F4* tp = tris + (size_t)first * 3;
+                loadsHaveArrived();           // (the look-up of `first`, and whatever a previous turn left unread)
                 // (a record's second float4 ends with the model index, which only the final hit needs)
                 const f4_t A0 = ld4(tp), C0 = ld4(tp + 2), A1 = ld4(tp + 3), C1 = ld4(tp + 5);
                 const f3_t B0 = ld3(tp + 1), B1 = ld3(tp + 4);
@@ -749,6 +758,7 @@ RT_DEV bool tracePool(SceneK& S, bool hasRay, V3 o, V3 d, bool cull, bool skipDe
                 triCount += (uint32_t)__builtin_popcountll(m);
             }
             fetchPriority(false);
+            loadsHaveArrived();
             timerB.stop(lds, 1);
         }
         __builtin_amdgcn_wave_barrier();
@@ -939,8 +949,9 @@ RT_DEV Surface resolveSurface(SceneK& S, V3 o, V3 d, const Closest& h, int renor
     if (h.kind == KIND_PLANE) {
         s.mat = loadMat(inGlobal(S.plnMat), h.idx);
         const F4* const normals = inGlobal(S.plnNormals) + 5 * h.idx + renorm;
-        s.normal = xyz(ld4(normals));
-        lightNormal = xyz(ld4(normals + 1));
+        const f3_t n0 = ld3(normals), n1 = ld3(normals + 1);      // (three words each: see ld3)
+        s.normal = mk(n0.x, n0.y, n0.z);
+        lightNormal = mk(n1.x, n1.y, n1.z);
         return s;
     }
     if (h.kind == KIND_SPHERE) {
