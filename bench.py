@@ -380,8 +380,10 @@ def main():
     # A context orders its tiles (and chooses the blocks to split) from the costs its previous frames recorded, ranked after
     # every eighth frame: forty frames per context (8 ms of config 3) bring that feedback to its steady state before the warm-up
     # steps the caller asked for (with eight, twenty timed steps after five warm-up steps took 0.218 instead of 0.209 ms each).
+    # The choice of blocks to split is looked at every 32nd frame while nothing is split: a frame that profits from splitting
+    # (config 2) is in its steady state after three such looks.
     for ctx, s, buf in lanes:
-        for _ in range(40):
+        for _ in range(104):
             if tiled:
                 ctx.render_tiles_device(w, h, rank, share, tiles[0].data_ptr(), tile_bytes, s.cuda_stream)
             else:
